@@ -1,0 +1,202 @@
+/*
+ * rt_api.h — C-ABI drop-in boundary for the render-loop hot path of
+ * SakibSaikia/CPURayTracer (src/spheres), MI355X-native implementation.
+ *
+ * The reference has no FFI: the replaceable statements are the two Parallel-STL
+ * algorithms inside SpheresApp::DrawBitmap
+ *     std::for_each(par, rays, hdr[id] += GetHitColor(ray,0) * exposure)   spheres-app.cpp:177-184
+ *     std::transform(par, hdr -> ldr: /n, ACES, gamma, XMStoreColor)       spheres-app.cpp:196-214
+ * plus the serial ray generation feeding them (GenerateRays, spheres-app.cpp:132-161).
+ * This header is what a binding for that path binds: plain C types, caller-owned
+ * host buffers, device memory owned by the handle.  Every entry point returns an
+ * int status (RT_OK == 0); rt_last_error() returns the message for the calling
+ * thread.  Calls on one handle are serialised by the caller; one handle per device.
+ *
+ * The library behind this header is librt_hip.so (cpuraytracer_amd/csrc/): hand
+ * written HIP for gfx950.  There is NO CPU fallback: rt_create fails loudly when
+ * no HIP device is present.  The CPU restatement used for parity checks lives in
+ * oracle/ behind oracle/oracle_api.h and shares only the POD records below.
+ */
+#ifndef RT_API_H
+#define RT_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_API_VERSION 1
+
+enum rt_status {
+    RT_OK = 0,
+    RT_ERR_NO_DEVICE = 1,     /* no HIP device / ordinal out of range              */
+    RT_ERR_INVALID_ARG = 2,   /* null pointer, zero size, bad range                */
+    RT_ERR_NO_SCENE = 3,      /* rt_render before rt_scene_upload                  */
+    RT_ERR_HIP = 4,           /* a HIP runtime call failed (see rt_last_error)     */
+    RT_ERR_OUT_OF_MEMORY = 5,
+    RT_ERR_SEQUENCE = 6       /* sample range does not continue the accumulation   */
+};
+
+/* ------------------------------------------------------------------ records */
+
+/* Sphere — common-lib/ray-tracing.h:53-57 (center, radius); material i belongs to sphere i. */
+typedef struct rt_sphere {
+    float cx, cy, cz, r;
+} rt_sphere; /* 16 B */
+
+/* Material kinds — common-lib/material.h:21,37,54,70 */
+enum rt_material_type {
+    RT_MAT_DIELECTRIC_OPAQUE = 0,
+    RT_MAT_METAL = 1,
+    RT_MAT_DIELECTRIC_TRANSPARENT = 2,
+    RT_MAT_EMISSIVE = 3
+};
+
+/* Texture kinds — common-lib/texture.h:12,22 */
+enum rt_texture_type {
+    RT_TEX_CONST = 0,
+    RT_TEX_CHECKER = 1
+};
+
+/* Material + its (single) texture, flattened.  Colours are the values the
+ * reference holds after XMLoadColor(XMCOLOR) (texture.cpp:5,16-17): byte * (1/255). */
+typedef struct rt_material {
+    uint32_t type;       /* rt_material_type                                         */
+    uint32_t tex_type;   /* rt_texture_type (opaque: albedo, metal: reflectance)     */
+    float smoothness;    /* m_smoothness (replicated scalar)                         */
+    float ior;           /* DielectricTransparent::m_ior                             */
+    float tiling;        /* CheckerTexture::m_tilingScale                            */
+    float rgb0[3];       /* ConstTexture colour / checker colour 0                   */
+    float rgb1[3];       /* checker colour 1                                         */
+    float luminance;     /* Emissive::m_luminance                                    */
+} rt_material; /* 48 B */
+
+/* Camera members after Camera::Camera — common-lib/camera.h:14-19, camera.cpp:3-28 */
+typedef struct rt_camera {
+    float origin[4];              /* m_origin            */
+    float x[4];                   /* m_x = halfWidth*u   */
+    float y[4];                   /* m_y = halfHeight*v  */
+    float origin_image_plane[4];  /* m_originImagePlane  */
+    float aperture;               /* m_aperture          */
+    float focal_length;           /* m_focalLength       */
+} rt_camera; /* 72 B */
+
+/* DirectionalLight members — common-lib/light.h:18-21, light.cpp:4-9 */
+typedef struct rt_light {
+    float direction[3];  /* normalised */
+    float color[3];      /* XMLoadColor of the ctor colour */
+    float luminance;
+} rt_light; /* 28 B */
+
+/* Rows of the W x H image this call renders.  The row range
+ * [first_row, first_row+num_rows) is cut into blocks of block_rows rows; the
+ * call owns the blocks b with b % nshards == shard (cyclic: cost is strongly
+ * row dependent).  Owned rows, in increasing order, are the "local rows" of the
+ * HDR/LDR strip.  {0, H, H, 0, 1} is the whole image. */
+typedef struct rt_rowset {
+    uint32_t first_row;
+    uint32_t num_rows;
+    uint32_t block_rows;
+    uint32_t shard;
+    uint32_t nshards;
+} rt_rowset;
+
+/* Counters a render call returns; traversals must equal the oracle's count. */
+typedef struct rt_stats {
+    uint64_t samples;      /* (pixel, s) paths traced                               */
+    uint64_t traversals;   /* ray-vs-whole-list scans: closest-hit + shadow         */
+    uint64_t segments;     /* closest-hit scans only (= ray segments)               */
+    double ms_render;      /* HIP-event time of the trace kernel(s)                 */
+    double ms_accumulate;  /* HIP-event time of the ordered accumulate kernel       */
+    double ms_resolve;     /* HIP-event time of the last rt_resolve                 */
+    uint32_t local_rows;   /* rows in this shard's strip                            */
+    uint32_t passes;       /* sample-range passes the call was split into           */
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+
+/* ------------------------------------------------------------- life cycle */
+
+const char* rt_last_error(void);
+int rt_api_version(void);
+
+/* One context per device ordinal.  Fails with RT_ERR_NO_DEVICE when there is no GPU. */
+int rt_create(int device_ordinal, rt_ctx** out);
+void rt_destroy(rt_ctx* ctx);
+
+/* Launch on a caller-provided hipStream_t (e.g. torch's current stream); NULL restores
+ * the context's own stream. */
+int rt_set_stream(rt_ctx* ctx, void* hip_stream);
+
+/* Upper bound for the per-sample workspace in bytes (default 8 GiB).  A render
+ * whose W*rows*(s1-s0)*12 bytes exceed it is split into sample-range passes. */
+int rt_set_workspace_limit(rt_ctx* ctx, uint64_t bytes);
+
+/* ------------------------------------------------------------------ scene */
+
+/* Replaces SpheresApp::InitScene's products (spheres-app.cpp:51-130): n spheres with
+ * their materials, the camera (InitCamera, :35-49), the sun, the sky Emissive
+ * material and exposureAdjustment = 2^m_exposure (:174). */
+int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* materials, uint32_t n,
+                    const rt_camera* camera, const rt_light* sun, const rt_material* sky,
+                    float exposure_scale);
+
+/* ----------------------------------------------------------------- render */
+
+/* Replaces GenerateRays + the for_each(par) trace loop for sample indices s in
+ * [s0, s1) (1-based like m_sampleCount, spheres-app.cpp:168) over the rows in rs.
+ * hdr[pixel] += GetHitColor(ray(i,j,s), 0) * exposure, added in increasing s
+ * (spheres-app.cpp:182-183).  The HDR strip persists in the context: a call with
+ * s0 == 1 (or after rt_clear) starts a new accumulation, a call whose s0 equals
+ * the previous s1 continues it (progressive refinement, app.h:26 + spheres-app.h:42).
+ * Material random draws come from a per-(pixel,s) xoshiro128** stream seeded from
+ * (seed, global pixel id, s) — see DESIGN.md "RNG contract". */
+int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1,
+              uint32_t max_depth, uint64_t seed, rt_stats* out_stats);
+
+/* Forget the accumulated HDR strip and sample count. */
+int rt_clear(rt_ctx* ctx);
+
+/* Replaces the transform(par) tonemap (spheres-app.cpp:186-214): hdr / n_samples,
+ * ACES fit, gamma 1/2.2, XMStoreColor.  n_samples == 0 uses the accumulated count. */
+int rt_resolve(rt_ctx* ctx, uint32_t n_samples);
+
+/* Copy the strip to host.  hdr_rgb: W*local_rows*3 floats; ldr_rgb: W*local_rows*3
+ * bytes (R,G,B of the XMCOLOR).  Either pointer may be NULL. */
+int rt_download(rt_ctx* ctx, float* hdr_rgb, uint8_t* ldr_rgb);
+
+/* Same, device to device into caller-owned device memory (e.g. a torch tensor that
+ * feeds the RCCL gather).  Asynchronous on the context's stream. */
+int rt_copy_to_device(rt_ctx* ctx, void* dev_hdr_rgb, void* dev_ldr_rgb);
+
+/* Block until everything queued on the context's stream has finished. */
+int rt_synchronize(rt_ctx* ctx);
+
+/* Global row index of local row lr under rs (pure host arithmetic; no GPU). */
+uint32_t rt_rowset_local_rows(rt_rowset rs);
+uint32_t rt_rowset_global_row(rt_rowset rs, uint32_t local_row);
+
+/* --------------------------------------------------- unit-level entry points
+ * Batched, device-evaluated pieces of the path, so that each reference function
+ * has a GPU-vs-oracle known-answer test (tests/test_gpu_units.py).  All buffers
+ * are host memory; n elements. */
+
+/* Random::HaltonSample — quasi-random.cpp:3-16 */
+int rt_unit_halton(rt_ctx* ctx, const uint32_t* index, uint32_t base, uint32_t n, float* out);
+/* op 0: sin, 1: cos, 2: pow(x,y) — the shared elementary-function contract */
+int rt_unit_math(rt_ctx* ctx, uint32_t op, const float* x, const float* y, uint32_t n, float* out);
+/* GenerateRays for chosen pixels: (i,j,s) -> origin xyz, direction xyz (6 floats each) */
+int rt_unit_primary_rays(rt_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* ijs /*3 per ray*/,
+                         uint32_t n, float* out_rays);
+/* Closest hit over the uploaded scene: rays (6 floats) -> t, index (as float bits), pos xyz,
+ * normal xyz, uv (10 floats each; index < 0 == miss) */
+int rt_unit_closest_hit(rt_ctx* ctx, const float* rays, uint32_t n, float* out_hits);
+/* Per-sample radiance*exposure for chosen (i,j,s): 3 floats each + traversal count */
+int rt_unit_trace(rt_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* ijs, uint32_t n,
+                  uint32_t max_depth, uint64_t seed, float* out_rgb, uint32_t* out_traversals);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_API_H */

@@ -1,0 +1,65 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY.  C ABI of the CPU restatement (liboracle.so), used by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker.  It shares the POD
+ * records of include/rt_api.h so the same flat scene feeds both the oracle and the HIP library.
+ * PARITY UNPINNED w.r.t. the original binary; pinned by tests/golden/halton_known_answers.json. */
+#ifndef ORACLE_API_H
+#define ORACLE_API_H
+#include "../include/rt_api.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_ctx orc_ctx;
+
+enum { ORC_ACCEL_LIST = 0, ORC_ACCEL_BVH = 1 };
+
+int orc_create(orc_ctx** out);
+void orc_destroy(orc_ctx* ctx);
+const char* orc_last_error(void);
+
+/* Scene generators (InitScene/InitCamera restated): name in {"cover","three","grid10k"}.
+ * cap = capacity of the spheres/materials arrays; *n receives the count (even when cap is too
+ * small, in which case nothing is written and 1 is returned). */
+int orc_build_scene(const char* name, uint64_t seed, float aspect, float aperture_override, uint32_t cap,
+                    rt_sphere* spheres, rt_material* materials, uint32_t* n, rt_camera* camera, rt_light* sun,
+                    rt_material* sky, float* exposure_scale);
+
+int orc_scene_upload(orc_ctx* ctx, const rt_sphere* spheres, const rt_material* materials, uint32_t n,
+                     const rt_camera* camera, const rt_light* sun, const rt_material* sky, float exposure_scale);
+int orc_render(orc_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1, uint32_t max_depth,
+               uint64_t seed, int accel, int threads, rt_stats* out_stats);
+int orc_clear(orc_ctx* ctx);
+int orc_resolve(orc_ctx* ctx, uint32_t n_samples);
+int orc_download(orc_ctx* ctx, float* hdr_rgb, uint8_t* ldr_rgb);
+uint32_t orc_rowset_local_rows(rt_rowset rs);
+uint32_t orc_rowset_global_row(rt_rowset rs, uint32_t local_row);
+
+/* unit-level functions (one per restated reference function) */
+float orc_halton(uint64_t index, uint32_t base);
+void orc_halton_disk(uint64_t index, uint32_t b1, uint32_t b2, float out[2]);
+void orc_halton_hemisphere(uint64_t index, uint32_t b1, uint32_t b2, float out[3]);
+int orc_unit_halton(const uint32_t* index, uint32_t base, uint32_t n, float* out);
+int orc_unit_math(uint32_t op, const float* x, const float* y, uint32_t n, float* out);
+void orc_camera_make(const float origin[3], const float look_at[3], float vfov, float aspect, float focal, float aperture,
+                     rt_camera* out);
+int orc_unit_primary_rays(orc_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* ijs, uint32_t n, float* out_rays);
+int orc_unit_closest_hit(orc_ctx* ctx, const float* rays, uint32_t n, int accel, float* out_hits);
+int orc_unit_trace(orc_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* ijs, uint32_t n, uint32_t max_depth, uint64_t seed,
+                   int accel, float* out_rgb, uint32_t* out_traversals);
+float orc_fresnel_term(float cos_incident, float ior);
+void orc_refract(const float incident[3], const float normal[3], float eta, float out[3]);
+void orc_reflect(const float incident[3], const float normal[3], float out[3]);
+uint32_t orc_color_pack(float r, float g, float b, float a);
+void orc_color_load(uint32_t argb, float out[4]);
+/* scatter one hit: material record + incoming ray + hit (pos, normal, uv) + 3 uniforms to consume in order.
+ * returns scattered flag; out: attenuation[3], dir[3], n_draws */
+int orc_unit_scatter(const rt_material* m, const float ray_dir[3], const float pos[3], const float normal[3], const float uv[2],
+                     const float draws[3], float out_atten[3], float out_dir[3], uint32_t* n_draws);
+void orc_xoshiro_seed(uint64_t seed, uint32_t pixel_id, uint32_t sample, uint32_t out_state[4]);
+void orc_xoshiro_draws(uint64_t seed, uint32_t pixel_id, uint32_t sample, uint32_t n, float* out);
+void orc_tonemap(const float hdr_rgb[3], uint32_t n_samples, uint8_t out_rgb[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,234 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/liboracle.so (the CPU restatement of the reference's render loop).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the
+product package (cpuraytracer_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+class RtSphere(C.Structure):
+    _fields_ = [("cx", C.c_float), ("cy", C.c_float), ("cz", C.c_float), ("r", C.c_float)]
+
+
+class RtMaterial(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("tex_type", C.c_uint32), ("smoothness", C.c_float), ("ior", C.c_float),
+                ("tiling", C.c_float), ("rgb0", C.c_float * 3), ("rgb1", C.c_float * 3), ("luminance", C.c_float)]
+
+
+class RtCamera(C.Structure):
+    _fields_ = [("origin", C.c_float * 4), ("x", C.c_float * 4), ("y", C.c_float * 4),
+                ("origin_image_plane", C.c_float * 4), ("aperture", C.c_float), ("focal_length", C.c_float)]
+
+
+class RtLight(C.Structure):
+    _fields_ = [("direction", C.c_float * 3), ("color", C.c_float * 3), ("luminance", C.c_float)]
+
+
+class RtRowset(C.Structure):
+    _fields_ = [("first_row", C.c_uint32), ("num_rows", C.c_uint32), ("block_rows", C.c_uint32),
+                ("shard", C.c_uint32), ("nshards", C.c_uint32)]
+
+
+class RtStats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("traversals", C.c_uint64), ("segments", C.c_uint64),
+                ("ms_render", C.c_double), ("ms_accumulate", C.c_double), ("ms_resolve", C.c_double),
+                ("local_rows", C.c_uint32), ("passes", C.c_uint32)]
+
+
+SPHERE_DTYPE = np.dtype([("cx", "<f4"), ("cy", "<f4"), ("cz", "<f4"), ("r", "<f4")])
+MATERIAL_DTYPE = np.dtype([("type", "<u4"), ("tex_type", "<u4"), ("smoothness", "<f4"), ("ior", "<f4"),
+                           ("tiling", "<f4"), ("rgb0", "<f4", (3,)), ("rgb1", "<f4", (3,)), ("luminance", "<f4")])
+assert SPHERE_DTYPE.itemsize == 16 and MATERIAL_DTYPE.itemsize == 48
+assert C.sizeof(RtSphere) == 16 and C.sizeof(RtMaterial) == 48 and C.sizeof(RtCamera) == 72 and C.sizeof(RtLight) == 28
+
+ACCEL_LIST, ACCEL_BVH = 0, 1
+
+
+def build(force=False):
+    """Compile liboracle.so with the committed Makefile (g++, -ffp-contract=off)."""
+    srcs = ["rt_oracle.cpp", "oracle_capi.cpp", "rt_oracle.h", "dxmath_restate.h", "oracle_api.h", "../include/rt_api.h"]
+    if not force and os.path.exists(_LIB_PATH):
+        lib_m = os.path.getmtime(_LIB_PATH)
+        if all(os.path.getmtime(os.path.join(_HERE, s)) <= lib_m for s in srcs):
+            return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_halton.restype = C.c_float
+        L.orc_halton.argtypes = [C.c_uint64, C.c_uint32]
+        L.orc_halton_disk.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+        L.orc_halton_hemisphere.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+        L.orc_fresnel_term.restype = C.c_float
+        L.orc_fresnel_term.argtypes = [C.c_float, C.c_float]
+        L.orc_color_pack.restype = C.c_uint32
+        L.orc_color_pack.argtypes = [C.c_float] * 4
+        L.orc_color_load.argtypes = [C.c_uint32, C.POINTER(C.c_float)]
+        L.orc_rowset_local_rows.restype = C.c_uint32
+        L.orc_rowset_local_rows.argtypes = [RtRowset]
+        L.orc_rowset_global_row.restype = C.c_uint32
+        L.orc_rowset_global_row.argtypes = [RtRowset, C.c_uint32]
+        L.orc_create.argtypes = [C.POINTER(C.c_void_p)]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_build_scene.argtypes = [C.c_char_p, C.c_uint64, C.c_float, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p,
+                                      C.POINTER(C.c_uint32), C.POINTER(RtCamera), C.POINTER(RtLight),
+                                      C.POINTER(RtMaterial), C.POINTER(C.c_float)]
+        L.orc_scene_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(RtCamera),
+                                       C.POINTER(RtLight), C.POINTER(RtMaterial), C.c_float]
+        L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, RtRowset, C.c_uint32, C.c_uint32, C.c_uint32,
+                                 C.c_uint64, C.c_int, C.c_int, C.POINTER(RtStats)]
+        L.orc_clear.argtypes = [C.c_void_p]
+        L.orc_resolve.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_unit_halton.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_unit_math.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_camera_make.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float,
+                                      C.c_float, C.POINTER(RtCamera)]
+        L.orc_unit_primary_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_unit_closest_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_unit_trace.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64,
+                                     C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_refract.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float)]
+        L.orc_reflect.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_unit_scatter.argtypes = [C.POINTER(RtMaterial), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                       C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                       C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        L.orc_xoshiro_seed.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.orc_xoshiro_draws.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_tonemap.argtypes = [C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint8)]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+
+
+class Scene:
+    """Flat scene tables (the rt_api.h records) as numpy arrays + ctypes structs."""
+
+    def __init__(self, spheres, materials, camera, sun, sky, exposure_scale, name="", seed=0):
+        self.spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+        self.materials = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
+        self.camera, self.sun, self.sky = camera, sun, sky
+        self.exposure_scale = float(exposure_scale)
+        self.name, self.seed = name, seed
+
+    @property
+    def n(self):
+        return int(self.spheres.shape[0])
+
+
+def build_scene(name, seed=1, aspect=1.5, aperture=-1.0):
+    """InitScene/InitCamera restated by the oracle: name in {'cover','three','grid10k'}."""
+    L = lib()
+    cap = 10100
+    sph = np.zeros(cap, dtype=SPHERE_DTYPE)
+    mat = np.zeros(cap, dtype=MATERIAL_DTYPE)
+    n = C.c_uint32(0)
+    cam, sun, sky, exp = RtCamera(), RtLight(), RtMaterial(), C.c_float(0)
+    _check(L.orc_build_scene(name.encode(), seed, aspect, aperture, cap, sph.ctypes.data, mat.ctypes.data, C.byref(n),
+                             C.byref(cam), C.byref(sun), C.byref(sky), C.byref(exp)))
+    return Scene(sph[:n.value].copy(), mat[:n.value].copy(), cam, sun, sky, exp.value, name, seed)
+
+
+def whole_image(H):
+    return RtRowset(0, H, H, 0, 1)
+
+
+class Oracle:
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(lib().orc_create(C.byref(self._h)))
+        self.W = self.rows = 0
+
+    def close(self):
+        if self._h:
+            lib().orc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, scene):
+        _check(lib().orc_scene_upload(self._h, scene.spheres.ctypes.data, scene.materials.ctypes.data, scene.n,
+                                      C.byref(scene.camera), C.byref(scene.sun), C.byref(scene.sky), scene.exposure_scale))
+
+    def render(self, W, H, s0, s1, max_depth, seed, rowset=None, accel=ACCEL_LIST, threads=1):
+        rs = rowset if rowset is not None else whole_image(H)
+        st = RtStats()
+        _check(lib().orc_render(self._h, W, H, rs, s0, s1, max_depth, seed, accel, threads, C.byref(st)))
+        self.W, self.rows = W, st.local_rows
+        return st
+
+    def resolve(self, n=0):
+        _check(lib().orc_resolve(self._h, n))
+
+    def download(self):
+        hdr = np.zeros((self.rows, self.W, 3), dtype=np.float32)
+        ldr = np.zeros((self.rows, self.W, 3), dtype=np.uint8)
+        _check(lib().orc_download(self._h, hdr.ctypes.data, ldr.ctypes.data))
+        return hdr, ldr
+
+    def primary_rays(self, W, H, ijs):
+        ijs = np.ascontiguousarray(ijs, dtype=np.uint32).reshape(-1, 3)
+        out = np.zeros((ijs.shape[0], 6), dtype=np.float32)
+        _check(lib().orc_unit_primary_rays(self._h, W, H, ijs.ctypes.data, ijs.shape[0], out.ctypes.data))
+        return out
+
+    def closest_hit(self, rays, accel=ACCEL_LIST):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        out = np.zeros((rays.shape[0], 10), dtype=np.float32)
+        _check(lib().orc_unit_closest_hit(self._h, rays.ctypes.data, rays.shape[0], accel, out.ctypes.data))
+        return out
+
+    def trace(self, W, H, ijs, max_depth, seed, accel=ACCEL_LIST):
+        ijs = np.ascontiguousarray(ijs, dtype=np.uint32).reshape(-1, 3)
+        rgb = np.zeros((ijs.shape[0], 3), dtype=np.float32)
+        trav = np.zeros(ijs.shape[0], dtype=np.uint32)
+        _check(lib().orc_unit_trace(self._h, W, H, ijs.ctypes.data, ijs.shape[0], max_depth, seed, accel, rgb.ctypes.data,
+                                    trav.ctypes.data))
+        return rgb, trav
+
+
+def halton_array(index, base):
+    index = np.ascontiguousarray(index, dtype=np.uint32)
+    out = np.zeros(index.shape[0], dtype=np.float32)
+    _check(lib().orc_unit_halton(index.ctypes.data, base, index.shape[0], out.ctypes.data))
+    return out
+
+
+def math_array(op, x, y=None):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), dtype=np.float32)
+    out = np.zeros_like(x)
+    _check(lib().orc_unit_math(op, x.ctypes.data, y.ctypes.data, x.shape[0], out.ctypes.data))
+    return out
+
+
+def write_ppm(path, ldr):
+    h, w, _ = ldr.shape
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (w, h))
+        f.write(np.ascontiguousarray(ldr, dtype=np.uint8).tobytes())

@@ -1,0 +1,828 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see rt_oracle.h).  CPU restatement of the reference hot path;
+// each function cites the reference file:line it follows.
+#include "rt_oracle.h"
+
+#include <algorithm>
+#include <cassert>
+#include <random>
+#include <string>
+#include <thread>
+
+namespace orc {
+
+// ============================================================== quasi-random.cpp
+namespace Random {
+
+// quasi-random.cpp:3-16 — float f, float accumulate, 64-bit index.
+float HaltonSample(uint64_t sampleIndex, uint32_t base) {
+    float result = 0.f;
+    float f = 1.f;
+    while (sampleIndex > 0) {
+        f = f / base;
+        result += f * (sampleIndex % base);
+        sampleIndex = sampleIndex / base;
+    }
+    return result;
+}
+
+// quasi-random.cpp:18-24
+XMFLOAT2 HaltonSample2D(uint64_t sampleIndex, uint32_t base1, uint32_t base2) {
+    return XMFLOAT2(HaltonSample(sampleIndex, base1), HaltonSample(sampleIndex, base2));
+}
+
+// quasi-random.cpp:26-34 (dead code in the reference; kept for the API surface)
+XMFLOAT2 HaltonSampleRing(uint64_t sampleIndex, uint32_t base) {
+    float theta = 2.f * XM_PI * HaltonSample(sampleIndex, base);
+    return XMFLOAT2(rt_cosf(theta), rt_sinf(theta));
+}
+
+// quasi-random.cpp:36-50 body, on two given uniforms: uniform in solid angle (NOT cosine weighted).
+XMFLOAT3 HemisphereFromUniforms(float u1, float u2) {
+    const float r = std::sqrt(1.f - u1 * u1);
+    const float phi = 2 * XM_PI * u2;
+    return XMFLOAT3(r * rt_cosf(phi), r * rt_sinf(phi), u1);
+}
+
+// quasi-random.cpp:36-50
+XMFLOAT3 HaltonSampleHemisphere(uint64_t sampleIndex, uint32_t base1, uint32_t base2) {
+    const float u1 = HaltonSample(sampleIndex, base1);
+    const float u2 = HaltonSample(sampleIndex, base2);
+    return HemisphereFromUniforms(u1, u2);
+}
+
+// quasi-random.cpp:52-61 — r is NOT sqrt'ed (centre-weighted disk).
+XMFLOAT2 HaltonSampleDisk(uint64_t sampleIndex, uint32_t base1, uint32_t base2) {
+    float theta = 2.f * XM_PI * HaltonSample(sampleIndex, base1);
+    float r = HaltonSample(sampleIndex, base2);
+    return XMFLOAT2(r * rt_cosf(theta), r * rt_sinf(theta));
+}
+
+static thread_local Xoshiro128* t_stream = nullptr;
+static thread_local const float* t_script = nullptr;
+static thread_local uint32_t t_scriptLen = 0, t_scriptUsed = 0;
+void BindPathStream(Xoshiro128* stream) { t_stream = stream; }
+void ScriptDraws(const float* draws, uint32_t n) { t_script = draws; t_scriptLen = n; t_scriptUsed = 0; }
+uint32_t ScriptDrawsUsed() { return t_scriptUsed; }
+float NextMaterialDraw() {
+    if (t_script) {
+        const float v = t_scriptUsed < t_scriptLen ? t_script[t_scriptUsed] : 0.f;
+        ++t_scriptUsed;
+        return v;
+    }
+    assert(t_stream && "material draw outside a bound path stream");
+    return t_stream->NextUniform();
+}
+
+}  // namespace Random
+
+static thread_local uint64_t t_traversals = 0;
+static thread_local uint64_t t_segments = 0;
+
+// ================================================================= ray-tracing.cpp
+// ray-tracing.cpp:15-19
+XMVECTOR Ray::Evaluate(float t) const { return XMVectorMultiplyAdd(direction, XMVectorReplicate(t), origin); }
+
+// ray-tracing.cpp:21-24
+Sphere::Sphere(const XMVECTOR& c, const float r, std::shared_ptr<const Material> mat) noexcept
+    : center{c}, radius{r}, material{std::move(mat)} {}
+
+// ray-tracing.cpp:26-40 — planar projection, y up.
+XMFLOAT2 Sphere::ComputeUV(const XMVECTOR& worldPos) const {
+    XMVECTOR unitSpherePos = (worldPos - center) / radius;
+    XMFLOAT3 pos;
+    XMStoreFloat3(&pos, unitSpherePos);
+    XMFLOAT2 uv;
+    uv.x = 0.5f * pos.x + 0.5f;
+    uv.y = 0.5f * pos.z + 0.5f;
+    return uv;
+}
+
+// ray-tracing.cpp:42-84 — first acceptable root wins.
+bool Sphere::Intersect(const Ray& ray, Payload& payload) const {
+    const XMVECTOR oc = ray.origin - center;
+    const XMVECTOR a = XMVector3Dot(ray.direction, ray.direction);
+    const XMVECTOR b = XMVector3Dot(oc, ray.direction);
+    const XMVECTOR c = XMVector3Dot(oc, oc) - XMVectorReplicate(radius * radius);
+    const XMVECTOR discriminant = b * b - a * c;
+    static const XMVECTORF32 bias{0.001f, 0.001f, 0.001f, 0.f};
+
+    if (XMVector3Greater(discriminant, ORC_XM_Zero)) {
+        XMVECTOR t = (-b - XMVectorSqrt(discriminant)) / a;
+        if (XMVector3Greater(t, bias)) {
+            payload.t = t;
+            payload.pos = XMVectorMultiplyAdd(t, ray.direction, ray.origin);
+            payload.normal = (payload.pos - center) / radius;
+            payload.uv = ComputeUV(payload.pos);
+            payload.material = material.get();
+            payload.index = index;
+            return true;
+        }
+        t = (-b + XMVectorSqrt(discriminant)) / a;
+        if (XMVector3Greater(t, bias)) {
+            payload.t = t;
+            payload.pos = XMVectorMultiplyAdd(t, ray.direction, ray.origin);
+            payload.normal = (payload.pos - center) / radius;
+            payload.uv = ComputeUV(payload.pos);
+            payload.material = material.get();
+            payload.index = index;
+            return true;
+        }
+    }
+    return false;
+}
+
+// ray-tracing.cpp:86-94
+AABB Sphere::GetAABB() const {
+    XMFLOAT3 origin;
+    XMStoreFloat3(&origin, center);
+    const XMFLOAT3 extents = {radius, radius, radius};
+    return AABB{origin, extents};
+}
+
+// ray-tracing.cpp:96-105
+AABB::AABB(const XMFLOAT3& center, const XMFLOAT3& extents) : m_box{center, extents} {}
+bool AABB::Intersect(const Ray& ray) const {
+    float t;
+    return m_box.Intersects(ray.origin, ray.direction, t);
+}
+
+// std::rand() in the reference is unseeded process state (ray-tracing.cpp:123); the oracle uses a
+// private LCG so the tree (not the image: closest hit is tree independent) is reproducible.
+static thread_local uint32_t t_bvhAxisState = 1u;
+static uint32_t BvhAxisRand() {
+    t_bvhAxisState = t_bvhAxisState * 1103515245u + 12345u;
+    return (t_bvhAxisState >> 16) & 0x7fff;
+}
+
+static XMFLOAT3 Sub3(XMFLOAT3 a, XMFLOAT3 b) { return XMFLOAT3(a.x - b.x, a.y - b.y, a.z - b.z); }  // ray-tracing.cpp:5-8
+
+// ray-tracing.cpp:107-167
+BvhNode::BvhNode(BvhNode::Iter begin, BvhNode::Iter end) {
+    size_t n = std::distance(begin, end);
+    if (n == 1) {
+        m_left = std::move(*begin);
+        m_right = nullptr;
+    } else if (n == 2) {
+        m_left = std::move(*begin);
+        m_right = std::move(*(begin + 1));
+    } else {
+        const int axis = (int)(BvhAxisRand() % 3);
+        std::sort(begin, end, [axis](const std::unique_ptr<Hitable>& a, const std::unique_ptr<Hitable>& b) {
+            XMFLOAT3 min_a = Sub3(a->GetAABB().m_box.Center, a->GetAABB().m_box.Extents);
+            XMFLOAT3 min_b = Sub3(b->GetAABB().m_box.Center, b->GetAABB().m_box.Extents);
+            return axis == 0 ? min_a.x < min_b.x : (axis == 1 ? min_a.y < min_b.y : min_a.z < min_b.z);
+        });
+        m_left = std::make_unique<BvhNode>(begin, begin + n / 2);
+        m_right = std::make_unique<BvhNode>(begin + n / 2, end);
+    }
+    if (m_right != nullptr) {
+        BoundingBox::CreateMerged(m_aabb.m_box, m_left->GetAABB().m_box, m_right->GetAABB().m_box);
+    } else {
+        m_aabb = m_left->GetAABB();
+    }
+}
+
+// ray-tracing.cpp:169-172
+AABB BvhNode::GetAABB() const { return m_aabb; }
+
+// ray-tracing.cpp:174-214 — both children always; both hit -> Less(left.t, right.t) ? left : right.
+bool BvhNode::Intersect(const Ray& ray, Payload& payload) const {
+    if (m_aabb.Intersect(ray)) {
+        Payload leftPayload, rightPayload;
+        bool leftHit = m_left->Intersect(ray, leftPayload);
+        bool rightHit = (m_right != nullptr ? m_right->Intersect(ray, rightPayload) : false);
+        if (leftHit && rightHit) {
+            if (XMVector3Less(leftPayload.t, rightPayload.t)) {
+                payload = leftPayload;
+            } else {
+                payload = rightPayload;
+            }
+            return true;
+        } else if (leftHit) {
+            payload = leftPayload;
+            return true;
+        } else if (rightHit) {
+            payload = rightPayload;
+            return true;
+        } else {
+            return false;
+        }
+    } else {
+        return false;
+    }
+}
+
+// List scan: every sphere tested with Sphere::Intersect; strict < keeps the
+// lower index on equal t.
+bool HitableList::Intersect(const Ray& ray, Payload& payload) const {
+    bool any = false;
+    Payload cand;
+    for (const auto& h : items) {
+        if (h->Intersect(ray, cand)) {
+            if (!any || cand.t.x < payload.t.x) {
+                payload = cand;
+                any = true;
+            }
+        }
+    }
+    return any;
+}
+
+// ===================================================================== texture.cpp
+ConstTexture::ConstTexture(const XMCOLOR& color) { m_color = XMLoadColor(&color); }  // texture.cpp:3-6
+XMVECTOR ConstTexture::Evaluate(XMFLOAT2) const { return m_color; }                  // texture.cpp:8-11
+
+// texture.cpp:13-18
+CheckerTexture::CheckerTexture(const XMCOLOR& color0, const XMCOLOR& color1, float tiling) : m_tilingScale{tiling} {
+    m_checkerColors[0] = XMLoadColor(&color0);
+    m_checkerColors[1] = XMLoadColor(&color1);
+}
+// texture.cpp:20-33 — int-truncated UV parity.
+XMVECTOR CheckerTexture::Evaluate(XMFLOAT2 uv) const {
+    const auto u = static_cast<int>(m_tilingScale * uv.x);
+    const auto v = static_cast<int>(m_tilingScale * uv.y);
+    if (u % 2 == v % 2) {
+        return m_checkerColors[0];
+    } else {
+        return m_checkerColors[1];
+    }
+}
+
+// ======================================================================= light.cpp
+// light.cpp:4-9
+DirectionalLight::DirectionalLight(const XMVECTOR& dir, const XMCOLOR& color, const float luminance,
+                                   std::function<bool(const Ray& ray)> lightOcclusionTest)
+    : m_luminance{luminance}, IsOccluded{std::move(lightOcclusionTest)} {
+    m_direction = XMVector3Normalize(dir);
+    m_color = XMLoadColor(&color);
+}
+DirectionalLight::DirectionalLight(const rt_light& flat, std::function<bool(const Ray& ray)> lightOcclusionTest)
+    : m_luminance{flat.luminance}, IsOccluded{std::move(lightOcclusionTest)} {
+    m_direction = XMVectorSet(flat.direction[0], flat.direction[1], flat.direction[2], 0.f);
+    m_color = XMVectorSet(flat.color[0], flat.color[1], flat.color[2], 1.f);
+}
+
+// light.cpp:11-42
+XMVECTOR DirectionalLight::Shade(const Material* material, const Payload& payload, const XMVECTOR& viewOrigin) const {
+    Ray shadowRay{payload.pos, m_direction};
+    if (IsOccluded(shadowRay)) {
+        return ORC_XM_Zero;
+    } else {
+        XMVECTOR albedo = material->GetAlbedo(payload.uv);
+        XMVECTOR f0 = material->GetReflectance(payload.uv);
+        XMVECTOR smoothness = material->GetSmoothness(payload.uv);
+
+        XMVECTOR nDotL = XMVectorSaturate(XMVector3Dot(payload.normal, m_direction));
+        XMVECTOR radianceIn = m_luminance * m_color * nDotL;
+
+        XMVECTOR diffuseBRDF = albedo;
+
+        XMVECTOR viewDir = XMVector3Normalize(viewOrigin - payload.pos);
+        XMVECTOR halfVector = XMVector3Normalize(m_direction + viewDir);
+        XMVECTOR nDotH = XMVectorSaturate(XMVector3Dot(payload.normal, halfVector));
+        XMVECTOR nDotV = XMVectorSaturate(XMVector3Dot(viewDir, payload.normal));
+        XMVECTOR reflectance = f0 + (ORC_XM_One - f0) * XMVectorPow(ORC_XM_One - nDotV, XMVectorReplicate(5.f));
+        XMVECTOR specularBRDF = reflectance * 0.125f * (smoothness + XMVectorReplicate(8.f)) * XMVectorPow(nDotH, smoothness);
+
+        return radianceIn * (diffuseBRDF + specularBRDF);
+    }
+}
+
+// ==================================================================== material.cpp
+// material.cpp:4-13
+XMVECTOR Material::Shade(const Payload& payload, const std::vector<std::unique_ptr<Light>>& lights, const XMVECTOR& viewOrigin) const {
+    XMVECTOR directLighting = ORC_XM_Zero;
+    for (const auto& light : lights) {
+        directLighting += light->Shade(this, payload, viewOrigin);
+    }
+    return directLighting;
+}
+
+// material.cpp:15-18
+DielectricOpaque::DielectricOpaque(const Texture* albedo, const XMVECTOR& smoothness) : m_albedo{albedo}, m_smoothness{smoothness} {}
+
+// material.cpp:20-65
+bool DielectricOpaque::Scatter(const Ray& ray, const Payload& hit, XMVECTOR& outAttenuation, Ray& outRay) const {
+    if (XMVector3Greater(XMVector3Dot(-ray.direction, hit.normal), ORC_XM_Zero)) {
+        XMVECTOR f0 = GetReflectance(hit.uv);
+        XMVECTOR nDotV = XMVectorSaturate(XMVector3Dot(-ray.direction, hit.normal));
+        XMVECTOR reflectance = f0 + (ORC_XM_One - f0) * XMVectorPow(ORC_XM_One - nDotV, XMVectorReplicate(5.f));
+
+        const XMVECTOR rand = XMVectorReplicate(Random::NextMaterialDraw());  // was HaltonSample(counter++, 3), :29
+        bool bReflect = XMVector3Greater(reflectance, rand);
+
+        if (bReflect) {
+            outAttenuation = ORC_XM_One;
+            const XMVECTOR reflectDir = XMVector3Normalize(XMVector3Reflect(ray.direction, hit.normal));
+            outRay = {hit.pos, reflectDir};
+            return true;
+        } else {
+            outAttenuation = m_albedo->Evaluate(hit.uv);
+
+            // was HaltonSampleHemisphere(counter++, 5, 7), :44 — two draws (u1, u2) in that order
+            const float u1 = Random::NextMaterialDraw();
+            const float u2 = Random::NextMaterialDraw();
+            XMFLOAT3 dir = Random::HemisphereFromUniforms(u1, u2);
+
+            XMVECTOR b3 = hit.normal;
+            XMFLOAT3 temp;
+            XMStoreFloat3(&temp, b3);
+            XMVECTOR up = std::fabs(temp.x) < 0.5f ? XMVECTORF32{1.0f, 0.0f, 0.0f, 0.f} : XMVECTORF32{0.0f, 1.0f, 0.0f, 0.f};
+            XMVECTOR b1 = XMVector3Cross(up, b3);
+            XMVECTOR b2 = XMVector3Cross(b3, b1);
+
+            const XMVECTOR scatterDir = dir.x * b1 + dir.y * b2 + dir.z * b3;
+            outRay = {hit.pos, XMVector3Normalize(scatterDir)};
+            return true;
+        }
+    } else {
+        return false;
+    }
+}
+
+// material.cpp:67-70
+Metal::Metal(const Texture* reflectance, const XMVECTOR& smoothness) : m_reflectance{reflectance}, m_smoothness{smoothness} {}
+
+// material.cpp:72-103 — four-lane coin (w lane of f0 is alpha = 1, so it always reflects).
+bool Metal::Scatter(const Ray& ray, const Payload& hit, XMVECTOR& outAttenuation, Ray& outRay) const {
+    if (XMVector3Greater(XMVector3Dot(-ray.direction, hit.normal), ORC_XM_Zero)) {
+        XMVECTOR f0 = GetReflectance(hit.uv);
+        XMVECTOR nDotV = XMVectorSaturate(XMVector3Dot(-ray.direction, hit.normal));
+        XMVECTOR reflectance = f0 + (ORC_XM_One - f0) * XMVectorPow(ORC_XM_One - nDotV, XMVectorReplicate(5.f));
+
+        uint32_t bReflect;
+        const XMVECTOR rand = XMVectorReplicate(Random::NextMaterialDraw());  // was HaltonSample(counter++, 3), :82
+        XMVectorGreaterR(&bReflect, reflectance, rand);
+
+        if (XMComparisonAnyTrue(bReflect)) {
+            outAttenuation = m_reflectance->Evaluate(hit.uv);
+            const XMVECTOR reflectDir = XMVector3Normalize(XMVector3Reflect(ray.direction, hit.normal));
+            outRay = {hit.pos, reflectDir};
+            return true;
+        } else {
+            return false;
+        }
+    } else {
+        return false;
+    }
+}
+
+// material.cpp:105-109
+DielectricTransparent::DielectricTransparent(const XMVECTOR& smoothness, const float ior) : m_smoothness{smoothness} {
+    m_ior = XMVectorReplicate(ior);
+}
+
+// material.cpp:111-164
+bool DielectricTransparent::Scatter(const Ray& ray, const Payload& hit, XMVECTOR& outAttenuation, Ray& outRay) const {
+    outAttenuation = {1.f, 1.f, 1.f, 0.f};
+
+    XMVECTOR outwardNormal{};
+    XMVECTOR niOverNt{};
+    XMVECTOR cosineIncidentAngle{};
+    XMVECTOR reflectionProbability{};
+
+    if (XMVector3Greater(XMVector3Dot(ray.direction, hit.normal), ORC_XM_Zero)) {
+        outwardNormal = -hit.normal;
+        niOverNt = m_ior;
+        cosineIncidentAngle = XMVector3Dot(ray.direction, hit.normal);
+    } else {
+        outwardNormal = hit.normal;
+        niOverNt = XMVectorReciprocalEst(m_ior);
+        cosineIncidentAngle = XMVector3Dot(ray.direction, -hit.normal);
+    }
+
+    XMVECTOR refractDir = XMVector3RefractV(ray.direction, outwardNormal, niOverNt);
+    bool canRefract = XMVector3NotEqual(refractDir, ORC_XM_Zero);
+
+    if (canRefract) {
+        reflectionProbability = XMFresnelTerm(cosineIncidentAngle, m_ior);
+    } else {
+        reflectionProbability = ORC_XM_One;
+    }
+
+    const XMVECTOR rand = XMVectorReplicate(Random::NextMaterialDraw());  // was HaltonSample(counter++, 7), :151
+
+    if (XMVector3Greater(reflectionProbability, rand)) {
+        const XMVECTOR reflectDir = XMVector3Normalize(XMVector3Reflect(ray.direction, hit.normal));
+        outRay = {hit.pos, reflectDir};
+        return true;
+    } else {
+        outRay = {hit.pos, XMVector3Normalize(refractDir)};
+        return true;
+    }
+}
+
+// material.cpp:166-175
+Emissive::Emissive(const float luminance, const Texture* color) : m_color{color}, m_luminance{luminance} {}
+XMVECTOR Emissive::Emit(const Payload& payload) const { return m_luminance * m_color->Evaluate(payload.uv); }
+
+// ====================================================================== camera.cpp
+// camera.cpp:3-28
+Camera::Camera(const XMVECTOR origin, const XMVECTOR lookAt, const float verticalFOV, const float aspectRatio,
+               const float focalLength, const float aperture)
+    : m_origin{origin}, m_aperture{aperture}, m_focalLength{focalLength} {
+    const float theta = verticalFOV * XM_PI / 180.f;
+    const float halfHeight = rt_tanf(theta / 2.f);
+    const float halfWidth = aspectRatio * halfHeight;
+
+    const XMVECTORF32 up{0.f, 1.f, 0.f, 0.f};
+    const XMVECTOR w = XMVector3Normalize(lookAt - origin);
+    const XMVECTOR u = XMVector3Normalize(XMVector3Cross(up, w));
+    const XMVECTOR v = XMVector3Cross(w, u);
+
+    const float imagePlaneOffset = 1.f;
+    m_originImagePlane = origin + imagePlaneOffset * w;
+    m_x = halfWidth * u;
+    m_y = halfHeight * v;
+}
+
+static XMVECTOR Load4(const float* p) { return XMVectorSet(p[0], p[1], p[2], p[3]); }
+static void Store4(float* p, XMVECTOR v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w; }
+
+Camera::Camera(const rt_camera& flat)
+    : m_origin{Load4(flat.origin)}, m_x{Load4(flat.x)}, m_y{Load4(flat.y)}, m_originImagePlane{Load4(flat.origin_image_plane)},
+      m_aperture{flat.aperture}, m_focalLength{flat.focal_length} {}
+
+rt_camera Camera::Flatten() const {
+    rt_camera c{};
+    Store4(c.origin, m_origin);
+    Store4(c.x, m_x);
+    Store4(c.y, m_y);
+    Store4(c.origin_image_plane, m_originImagePlane);
+    c.aperture = m_aperture;
+    c.focal_length = m_focalLength;
+    return c;
+}
+
+// camera.cpp:30-48
+Ray Camera::GetRay(XMFLOAT2 uv, XMFLOAT2 offset) const {
+    XMFLOAT2 ndc;
+    ndc.x = 2.f * uv.x - 1.f;
+    ndc.y = -2.f * uv.y + 1.f;
+
+    const XMVECTOR p = m_originImagePlane + ndc.x * m_x + ndc.y * m_y;
+    const XMVECTOR focalPoint = m_origin + m_focalLength * XMVector3Normalize(p - m_origin);
+
+    XMFLOAT2 rd;
+    rd.x = 0.5f * m_aperture * offset.x;
+    rd.y = 0.5f * m_aperture * offset.y;
+    const XMVECTOR origin = m_origin + rd.x * m_x + rd.y * m_y;
+
+    return Ray{origin, XMVector3Normalize(focalPoint - origin)};
+}
+
+// camera.cpp:50-53
+XMVECTOR Camera::GetOrigin() const { return m_origin; }
+
+// ================================================================== spheres-app.cpp
+uint32_t RowsetLocalRows(rt_rowset rs) {
+    if (rs.block_rows == 0 || rs.nshards == 0 || rs.shard >= rs.nshards) return 0;
+    uint32_t rows = 0;
+    const uint32_t nblocks = (rs.num_rows + rs.block_rows - 1) / rs.block_rows;
+    for (uint32_t b = rs.shard; b < nblocks; b += rs.nshards) {
+        const uint32_t r0 = b * rs.block_rows;
+        rows += std::min(rs.block_rows, rs.num_rows - r0);
+    }
+    return rows;
+}
+uint32_t RowsetGlobalRow(rt_rowset rs, uint32_t localRow) {
+    const uint32_t lb = localRow / rs.block_rows;  // all owned blocks but possibly the last are full
+    const uint32_t k = localRow % rs.block_rows;
+    return rs.first_row + (lb * rs.nshards + rs.shard) * rs.block_rows + k;
+}
+
+static XMCOLOR ColorFromLoaded(const float* rgb) {
+    // rgb holds byte*(1/255); XMCOLOR's ctor re-quantises to the same byte.
+    return XMCOLOR(rgb[0], rgb[1], rgb[2], 1.f);
+}
+
+void SpheresApp::LoadScene(const FlatScene& flat, uint64_t bvhAxisSeed) {
+    m_textures.clear();
+    m_lights.clear();
+    m_camera = std::make_unique<Camera>(flat.camera);
+    m_exposureScale = flat.exposureScale;
+
+    auto makeMaterial = [this](const rt_material& m) -> std::shared_ptr<const Material> {
+        const Texture* tex = nullptr;
+        if (m.type != RT_MAT_DIELECTRIC_TRANSPARENT) {
+            if (m.tex_type == RT_TEX_CHECKER) {
+                m_textures.push_back(std::make_unique<CheckerTexture>(ColorFromLoaded(m.rgb0), ColorFromLoaded(m.rgb1), m.tiling));
+            } else {
+                m_textures.push_back(std::make_unique<ConstTexture>(ColorFromLoaded(m.rgb0)));
+            }
+            tex = m_textures.back().get();
+        }
+        switch (m.type) {
+            case RT_MAT_METAL: return std::make_shared<Metal>(tex, XMVectorReplicate(m.smoothness));
+            case RT_MAT_DIELECTRIC_TRANSPARENT: return std::make_shared<DielectricTransparent>(XMVectorReplicate(m.smoothness), m.ior);
+            case RT_MAT_EMISSIVE: return std::make_shared<Emissive>(m.luminance, tex);
+            default: return std::make_shared<DielectricOpaque>(tex, XMVectorReplicate(m.smoothness));
+        }
+    };
+
+    m_sceneList = std::make_unique<HitableList>();
+    std::vector<std::unique_ptr<Hitable>> forBvh;
+    for (size_t i = 0; i < flat.spheres.size(); ++i) {
+        const rt_sphere& s = flat.spheres[i];
+        auto mat = makeMaterial(flat.materials[i]);
+        auto a = std::make_unique<Sphere>(XMVectorSet(s.cx, s.cy, s.cz, 0.f), s.r, mat);
+        a->index = (int)i;
+        auto b = std::make_unique<Sphere>(XMVectorSet(s.cx, s.cy, s.cz, 0.f), s.r, mat);
+        b->index = (int)i;
+        m_sceneList->items.push_back(std::move(a));
+        forBvh.push_back(std::move(b));
+    }
+    // spheres-app.cpp:117 — BvhNode takes ownership by moving out of the vector.
+    t_bvhAxisState = (uint32_t)(bvhAxisSeed * 2654435761u + 1u);
+    m_bvh = forBvh.empty() ? nullptr : std::make_unique<BvhNode>(forBvh.begin(), forBvh.end());
+
+    // spheres-app.cpp:120-121 — sky
+    m_textures.push_back(std::make_unique<ConstTexture>(ColorFromLoaded(flat.sky.rgb0)));
+    m_skyMaterial = std::make_unique<Emissive>(flat.sky.luminance, m_textures.back().get());
+
+    // spheres-app.cpp:124-129 — sun, occlusion test = any hit through the active accelerator
+    auto lightOcclusionTest = [this](const Ray& ray) -> bool {
+        Payload dummy{};
+        ++t_traversals;
+        return m_activeAccel->Intersect(ray, dummy);
+    };
+    m_lights.push_back(std::make_unique<DirectionalLight>(flat.sun, lightOcclusionTest));
+    m_activeAccel = m_sceneList.get();
+    Clear();
+}
+
+// spheres-app.cpp:132-161 for one pixel.  jitter = Halton2D(s;2,3) is the same for every pixel.
+Ray SpheresApp::GeneratePrimaryRay(uint32_t W, uint32_t H, uint32_t i, uint32_t j, uint32_t s) const {
+    const auto xsize = static_cast<float>(W);
+    const auto ysize = static_cast<float>(H);
+    XMFLOAT2 jitterOffset = Random::HaltonSample2D(s, 2, 3);
+    XMFLOAT2 uv;
+    uv.x = static_cast<float>(static_cast<int>(i) + jitterOffset.x) / xsize;
+    uv.y = static_cast<float>(static_cast<int>(j) + jitterOffset.y) / ysize;
+    const XMFLOAT2 offset = Random::HaltonSampleDisk((uint64_t)s + i + j, 4, 5);
+    return m_camera->GetRay(uv, offset);
+}
+
+// spheres-app.cpp:224-236
+std::optional<Payload> SpheresApp::GetClosestIntersection(const Ray& ray) const {
+    Payload payload{};
+    ++t_traversals;
+    ++t_segments;
+    if (m_activeAccel->Intersect(ray, payload)) {
+        return payload;
+    } else {
+        return std::nullopt;
+    }
+}
+
+// spheres-app.cpp:238-257, iterative: L = E0+S0 + a0*(E1+S1 + a1*(...)) carried as
+// radiance += throughput*(E+S); throughput *= attenuation.  Scatter is called FIRST (:246) and
+// still draws at depth == limit (:246-247).  Shade always receives the CAMERA origin (:250).
+XMVECTOR SpheresApp::GetHitColor(const Ray& ray0, int depth0) const {
+    XMVECTOR radiance = ORC_XM_Zero;
+    XMVECTOR throughput = ORC_XM_One;
+    Ray ray = ray0;
+    for (int depth = depth0;; ++depth) {
+        if (auto hitInfo = GetClosestIntersection(ray)) {
+            const Payload& hit = hitInfo.value();
+            XMVECTOR attenuation;
+            Ray scatteredRay;
+            const bool isScattered = hit.material->Scatter(ray, hit, attenuation, scatteredRay);
+            const bool recurse = depth < m_maxDepth && isScattered;
+            const XMVECTOR local = hit.material->Emit(hit) + hit.material->Shade(hit, m_lights, m_camera->GetOrigin());
+            radiance = radiance + throughput * local;
+            if (!recurse) break;
+            throughput = throughput * attenuation;
+            ray = scatteredRay;
+        } else {
+            radiance = radiance + throughput * m_skyMaterial->Emit(Payload{});
+            break;
+        }
+    }
+    return radiance;
+}
+
+XMVECTOR SpheresApp::TraceSample(uint32_t W, uint32_t H, uint32_t i, uint32_t j, uint32_t s, uint32_t maxDepth, uint64_t seed,
+                                 Accel accel, uint32_t* traversals) const {
+    m_activeAccel = (accel == Accel::Bvh) ? static_cast<const Hitable*>(m_bvh.get()) : m_sceneList.get();
+    m_maxDepth = (int)maxDepth;
+    Xoshiro128 stream;
+    stream.Seed(seed, j * W + i, s);
+    Random::BindPathStream(&stream);
+    const uint64_t t0 = t_traversals;
+    const Ray ray = GeneratePrimaryRay(W, H, i, j, s);
+    const XMVECTOR c = GetHitColor(ray, 0) * m_exposureScale;  // spheres-app.cpp:183
+    Random::BindPathStream(nullptr);
+    if (traversals) *traversals = (uint32_t)(t_traversals - t0);
+    return c;
+}
+
+void SpheresApp::Clear() {
+    m_sampleCount = 0;
+    m_backbufferHdr.clear();
+    m_backbufferLdr.clear();
+    m_stripW = m_stripRows = 0;
+}
+
+// spheres-app.cpp:163-184 over sample indices [s0, s1): hdr[id] += GetHitColor(ray,0) * exposure,
+// per pixel in increasing s.  std::execution::par -> std::thread workers pulling local rows.
+void SpheresApp::Render(uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1, uint32_t maxDepth, uint64_t seed,
+                        Accel accel, int threads, RenderCounters& counters) {
+    const uint32_t rows = RowsetLocalRows(rs);
+    if (m_stripW != W || m_stripRows != rows || m_backbufferHdr.empty()) {
+        // app.cpp:112-119 InitBuffers
+        m_backbufferHdr.assign((size_t)W * rows, ORC_XM_Zero);
+        m_backbufferLdr.assign((size_t)W * rows, XMCOLOR(0.f, 0.f, 0.f, 0.f));
+        m_stripW = W;
+        m_stripRows = rows;
+        m_sampleCount = 0;
+    }
+    m_activeAccel = (accel == Accel::Bvh) ? static_cast<const Hitable*>(m_bvh.get()) : m_sceneList.get();
+    m_maxDepth = (int)maxDepth;
+
+    std::atomic<uint32_t> nextRow{0};
+    std::atomic<uint64_t> totalTraversals{0}, totalSegments{0};
+    auto worker = [&]() {
+        t_traversals = 0;
+        t_segments = 0;
+        for (;;) {
+            const uint32_t lr = nextRow.fetch_add(1);
+            if (lr >= rows) break;
+            const uint32_t j = RowsetGlobalRow(rs, lr);
+            for (uint32_t i = 0; i < W; ++i) {
+                XMVECTOR& colorVec = m_backbufferHdr[(size_t)lr * W + i];
+                for (uint32_t s = s0; s < s1; ++s) {
+                    Xoshiro128 stream;
+                    stream.Seed(seed, j * W + i, s);
+                    Random::BindPathStream(&stream);
+                    const Ray ray = GeneratePrimaryRay(W, H, i, j, s);
+                    colorVec += GetHitColor(ray, 0) * m_exposureScale;
+                }
+            }
+        }
+        Random::BindPathStream(nullptr);
+        totalTraversals += t_traversals;
+        totalSegments += t_segments;
+    };
+    if (threads <= 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+        for (auto& th : pool) th.join();
+    }
+    m_sampleCount += (s1 - s0);
+    counters.samples += (uint64_t)W * rows * (s1 - s0);
+    counters.traversals += totalTraversals.load();
+    counters.segments += totalSegments.load();
+}
+
+// spheres-app.cpp:186-214 for one pixel
+XMCOLOR SpheresApp::TonemapColor(const XMVECTOR& hdrColor, uint32_t n) {
+    static const float a = 2.51f;
+    static const float b = 0.03f;
+    static const float c = 2.43f;
+    static const float d = 0.59f;
+    static const float e = 0.14f;
+    static XMVECTORF32 invGamma{1 / 2.2f, 1 / 2.2f, 1 / 2.2f, 0.f};
+    XMVECTOR color = hdrColor / static_cast<float>(n);
+    color.w = 0.f;  // the reference's w lane is garbage (sky w = 8000) and never displayed
+    color = XMVectorSaturate((color * (a * color + XMVectorReplicate(b))) / (color * (c * color + XMVectorReplicate(d)) + XMVectorReplicate(e)));
+    color = XMVectorPow(color, invGamma);
+    XMCOLOR outColor;
+    XMStoreColor(&outColor, color);
+    return outColor;
+}
+void SpheresApp::TonemapPixel(const float hdrRgb[3], uint32_t nSamples, uint8_t outRgb[3]) {
+    const XMCOLOR c = TonemapColor(XMVectorSet(hdrRgb[0], hdrRgb[1], hdrRgb[2], 0.f), nSamples);
+    outRgb[0] = (uint8_t)((c.c >> 16) & 0xff);
+    outRgb[1] = (uint8_t)((c.c >> 8) & 0xff);
+    outRgb[2] = (uint8_t)(c.c & 0xff);
+}
+void SpheresApp::Resolve(uint32_t nSamples) {
+    const uint32_t n = nSamples ? nSamples : m_sampleCount;
+    for (size_t k = 0; k < m_backbufferHdr.size(); ++k) m_backbufferLdr[k] = TonemapColor(m_backbufferHdr[k], n);
+}
+
+std::optional<Payload> SpheresApp::ClosestHitWith(const Ray& ray, Accel accel) const {
+    m_activeAccel = (accel == Accel::Bvh) ? static_cast<const Hitable*>(m_bvh.get()) : m_sceneList.get();
+    return GetClosestIntersection(ray);
+}
+const Material* SpheresApp::MaterialOf(size_t sphereIndex) const {
+    return static_cast<const Sphere*>(m_sceneList->items[sphereIndex].get())->material.get();
+}
+
+// ============================================================ scene generators (A18)
+// spheres-app.cpp:35-49 InitCamera and :51-130 InitScene, with std::ranlux24_base(seed) (portable:
+// fully specified by the C++ standard) and u = engine() * 2^-24 replacing
+// uniform_real_distribution<float> (implementation defined) — SURVEY.md §8(d).
+namespace {
+struct SceneBuilder {
+    FlatScene& out;
+    static void LoadRgb(float* dst, const XMCOLOR& c) {
+        const XMVECTOR v = XMLoadColor(&c);
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z;
+    }
+    void AddOpaque(float cx, float cy, float cz, float r, const XMCOLOR& albedo, float smoothness) {
+        rt_material m{};
+        m.type = RT_MAT_DIELECTRIC_OPAQUE; m.tex_type = RT_TEX_CONST; m.smoothness = smoothness;
+        LoadRgb(m.rgb0, albedo);
+        out.spheres.push_back({cx, cy, cz, r});
+        out.materials.push_back(m);
+    }
+    void AddOpaqueChecker(float cx, float cy, float cz, float r, const XMCOLOR& c0, const XMCOLOR& c1, float tiling, float smoothness) {
+        rt_material m{};
+        m.type = RT_MAT_DIELECTRIC_OPAQUE; m.tex_type = RT_TEX_CHECKER; m.smoothness = smoothness; m.tiling = tiling;
+        LoadRgb(m.rgb0, c0); LoadRgb(m.rgb1, c1);
+        out.spheres.push_back({cx, cy, cz, r});
+        out.materials.push_back(m);
+    }
+    void AddMetal(float cx, float cy, float cz, float r, const XMCOLOR& refl) {
+        rt_material m{};
+        m.type = RT_MAT_METAL; m.tex_type = RT_TEX_CONST; m.smoothness = 0.f;  // XM_Zero, spheres-app.cpp:96
+        LoadRgb(m.rgb0, refl);
+        out.spheres.push_back({cx, cy, cz, r});
+        out.materials.push_back(m);
+    }
+    void AddGlass(float cx, float cy, float cz, float r, float smoothness, float ior) {
+        rt_material m{};
+        m.type = RT_MAT_DIELECTRIC_TRANSPARENT; m.tex_type = RT_TEX_CONST; m.smoothness = smoothness; m.ior = ior;
+        out.spheres.push_back({cx, cy, cz, r});
+        out.materials.push_back(m);
+    }
+    void SkySunExposure() {
+        out.sky = rt_material{};
+        out.sky.type = RT_MAT_EMISSIVE; out.sky.tex_type = RT_TEX_CONST; out.sky.luminance = 8000.f;  // spheres-app.cpp:120-121
+        LoadRgb(out.sky.rgb0, XMCOLOR{0.85f, 0.91f, 0.98f, 1.f});
+        // spheres-app.cpp:129 + light.cpp:4-9
+        const XMVECTOR dir = XMVector3Normalize(XMVECTORF32{1.f, 1.f, 1.f, 0.f});
+        out.sun.direction[0] = dir.x; out.sun.direction[1] = dir.y; out.sun.direction[2] = dir.z;
+        LoadRgb(out.sun.color, XMCOLOR{1.f, 0.97f, 0.88f, 1.f});
+        out.sun.luminance = 40000.f;
+        out.exposureScale = std::ldexp(1.0f, -15);  // m_exposure = -15 (:48), std::pow(2, m_exposure) (:174)
+    }
+    // The per-cell rule of spheres-app.cpp:64-105 over a,b in [lo, hi).
+    void RandomSmallSpheres(std::ranlux24_base& generator, int lo, int hi) {
+        auto uniformDist = [&generator]() -> float { return (float)generator() * 0x1p-24f; };
+        for (int a = lo; a < hi; ++a) {
+            for (int b = lo; b < hi; ++b) {
+                const float chooseMat = uniformDist();
+                const float cx = a + 0.9f * uniformDist();
+                const float cz = b + 0.9f * uniformDist();
+                if (chooseMat < 0.8f) {
+                    const float r0 = uniformDist(), r1 = uniformDist(), g0 = uniformDist(), g1 = uniformDist(), b0 = uniformDist(), b1 = uniformDist();
+                    const XMCOLOR col{r0 * r1, g0 * g1, b0 * b1, 1.f};
+                    float smoothness = 8.f * (4.f + uniformDist());
+                    AddOpaque(cx, 0.2f, cz, 0.2f, col, smoothness);
+                } else if (chooseMat < 0.95f) {
+                    const float r = uniformDist(), g = uniformDist(), bb = uniformDist();
+                    const XMCOLOR col{0.5f * (1.f + r), 0.5f * (1.f + g), 0.5f * (1.f + bb), 1.f};
+                    AddMetal(cx, 0.2f, cz, 0.2f, col);
+                } else {
+                    float smoothness = 8.f * (4.f + uniformDist());
+                    AddGlass(cx, 0.2f, cz, 0.2f, smoothness, 1.5f);
+                }
+            }
+        }
+    }
+};
+}  // namespace
+
+bool BuildNamedScene(const char* nameC, uint64_t seed, float aspect, float apertureOverride, FlatScene& out) {
+    const std::string name(nameC ? nameC : "");
+    out = FlatScene{};
+    SceneBuilder sb{out};
+    if (name == "cover" || name == "grid10k") {
+        std::ranlux24_base generator((std::ranlux24_base::result_type)seed);
+        // Floor, spheres-app.cpp:60-61
+        sb.AddOpaqueChecker(0.f, -1000.f, 0.f, 1000.f, XMCOLOR{0.9f, 0.9f, 0.9f, 1.f}, XMCOLOR{0.2f, 0.3f, 0.1f, 1.f}, 2500.f, 16.f);
+        if (name == "cover") sb.RandomSmallSpheres(generator, -11, 11);
+        else sb.RandomSmallSpheres(generator, -50, 50);
+        // Large spheres, spheres-app.cpp:108-114
+        sb.AddGlass(0.f, 1.f, 0.f, 1.f, 16.f, 1.5f);
+        sb.AddOpaque(-4.f, 1.f, 0.f, 1.f, XMCOLOR{0.4f, 0.2f, 0.1f, 1.f}, 16.f);
+        sb.AddMetal(4.f, 1.f, 0.f, 1.f, XMCOLOR{0.7f, 0.6f, 0.5f, 1.f});
+        sb.SkySunExposure();
+        // InitCamera, spheres-app.cpp:35-49
+        const XMVECTOR camOrigin = XMVectorSet(12.f, 2.f, -2.5f, 1.f);
+        const XMVECTOR camLookAt = XMVectorSet(0, 1, 0, 1.f);
+        const float aperture = apertureOverride >= 0.f ? apertureOverride : 0.4f;
+        Camera cam(camOrigin, camLookAt, 25.f, aspect, XMVectorGetX(XMVector3Length(camOrigin - camLookAt)), aperture);
+        out.camera = cam.Flatten();
+        return true;
+    }
+    if (name == "three") {
+        // three DielectricOpaque spheres, pinhole camera.
+        sb.AddOpaque(0.f, 0.f, 1.f, 0.5f, XMCOLOR{0.5f, 0.5f, 0.5f, 1.f}, 16.f);
+        sb.AddOpaque(1.f, 0.f, 1.f, 0.5f, XMCOLOR{0.8f, 0.3f, 0.3f, 1.f}, 16.f);
+        sb.AddOpaque(0.f, -100.5f, 1.f, 100.f, XMCOLOR{0.8f, 0.8f, 0.0f, 1.f}, 16.f);
+        sb.SkySunExposure();
+        const float aperture = apertureOverride >= 0.f ? apertureOverride : 0.f;
+        Camera cam(XMVectorSet(0.f, 0.f, 0.f, 1.f), XMVectorSet(0.f, 0.f, 1.f, 1.f), 90.f, aspect, 1.f, aperture);
+        out.camera = cam.Flatten();
+        return true;
+    }
+    return false;
+}
+
+}  // namespace orc
