@@ -1,0 +1,514 @@
+// rt_capi.hip — C-ABI implementation (include/rt_api.h) over the HIP kernels in rt_kernels.h.
+// Builds into librt_hip.so with hipcc --offload-arch=gfx950.  No CPU fallback exists: every entry
+// point that needs the device fails with RT_ERR_NO_DEVICE / RT_ERR_HIP when it is absent.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_api.h"
+#include "rt_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int Fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define RT_HIP(call)                                                                                             \
+    do {                                                                                                         \
+        hipError_t e_ = (call);                                                                                  \
+        if (e_ != hipSuccess) {                                                                                  \
+            return Fail(e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP,                           \
+                        std::string(#call) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+        }                                                                                                        \
+    } while (0)
+
+uint32_t EnvU32(const char* name, uint32_t dflt) {
+    const char* v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    return (uint32_t)std::strtoul(v, nullptr, 10);
+}
+
+template <typename T>
+struct DevBuf {
+    T* ptr = nullptr;
+    size_t count = 0;
+    int Reserve(size_t n) {
+        if (n <= count) return RT_OK;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T));
+        if (e != hipSuccess) return Fail(RT_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+        count = n;
+        return RT_OK;
+    }
+    void Release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int cuCount = 0;
+    size_t ldsPerBlockMax = 0;
+    uint64_t workspaceLimit = 8ull << 30;
+
+    // scene
+    bool hasScene = false;
+    uint32_t n = 0;
+    DevBuf<float4> scan;
+    DevBuf<float> radius;
+    DevBuf<rt_material> mats;
+    rtd::TraceParams base{};  // scene part filled at upload
+
+    // accumulation state
+    uint32_t W = 0, H = 0, rows = 0;
+    rt_rowset rs{};
+    uint32_t accumulated = 0;  // samples accumulated so far (next s0 must be accumulated + 1)
+    DevBuf<float> hdr;         // [W*rows*3]
+    DevBuf<uint8_t> ldr;       // [W*rows*3]
+    DevBuf<float> samples;     // workspace [pixels*spp_pass*3]
+    DevBuf<uint32_t> queue;    // [1]
+    DevBuf<unsigned long long> counters;  // [2]
+    double lastResolveMs = 0.0;
+
+    // tuning (env: RT_BLOCKS_PER_CU, RT_FORCE_GLOBAL_TABLES)
+    uint32_t blocksPerCu = 4;
+    bool forceGlobal = false;
+};
+
+static uint32_t RowsetLocalRows(rt_rowset rs) {
+    if (rs.block_rows == 0 || rs.nshards == 0 || rs.shard >= rs.nshards) return 0;
+    uint32_t rows = 0;
+    const uint32_t nblocks = (rs.num_rows + rs.block_rows - 1) / rs.block_rows;
+    for (uint32_t b = rs.shard; b < nblocks; b += rs.nshards) {
+        const uint32_t r0 = b * rs.block_rows;
+        const uint32_t left = rs.num_rows - r0;
+        rows += left < rs.block_rows ? left : rs.block_rows;
+    }
+    return rows;
+}
+
+static uint32_t PaddedCount(uint32_t n) { return ((n + 7u) / 8u) * 8u + 4u; }
+static size_t LdsBytesFor(uint32_t n) { return (size_t)PaddedCount(n) * 16 + (size_t)n * (48 + 4); }
+
+// Launch the megakernel over total paths described by tp.
+static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
+    RT_HIP(hipMemsetAsync(ctx->queue.ptr, 0, sizeof(uint32_t), ctx->stream));
+    const size_t lds = LdsBytesFor(tp.n);
+    const bool useLds = !ctx->forceGlobal && lds <= 64 * 1024;
+    const uint32_t maxBlocks = (uint32_t)ctx->cuCount * ctx->blocksPerCu;
+    // one wave holds 64 paths; do not launch more waves than there is work for
+    const uint64_t wavesNeeded = ((uint64_t)tp.total_paths + 63) / 64;
+    uint32_t blocks = (uint32_t)((wavesNeeded + 3) / 4);
+    if (blocks > maxBlocks) blocks = maxBlocks;
+    if (blocks == 0) blocks = 1;
+    if (useLds) {
+        hipLaunchKernelGGL(rtd::rt_trace_kernel<true>, dim3(blocks), dim3(256), lds, ctx->stream, tp);
+    } else {
+        hipLaunchKernelGGL(rtd::rt_trace_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, tp);
+    }
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+namespace {
+template <typename T>
+struct TmpDev {
+    T* p = nullptr;
+    ~TmpDev() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t Alloc(size_t n) { return hipMalloc(reinterpret_cast<void**>(&p), (n ? n : 1) * sizeof(T)); }
+};
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+int rt_api_version(void) { return RT_API_VERSION; }
+
+int rt_create(int device_ordinal, rt_ctx** out) {
+    if (!out) return Fail(RT_ERR_INVALID_ARG, "rt_create: null out");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return Fail(RT_ERR_NO_DEVICE, std::string("rt_create: no HIP device (") + hipGetErrorString(e) +
+                                          "); this library has no CPU fallback");
+    if (device_ordinal < 0 || device_ordinal >= count) return Fail(RT_ERR_NO_DEVICE, "rt_create: device ordinal out of range");
+    RT_HIP(hipSetDevice(device_ordinal));
+    rt_ctx* ctx = new rt_ctx();
+    ctx->device = device_ordinal;
+    hipDeviceProp_t prop;
+    RT_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+    ctx->cuCount = prop.multiProcessorCount;
+    ctx->ldsPerBlockMax = prop.sharedMemPerBlock;
+    RT_HIP(hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking));
+    ctx->stream = ctx->ownStream;
+    for (auto& ev : ctx->ev) RT_HIP(hipEventCreate(&ev));
+    ctx->blocksPerCu = EnvU32("RT_BLOCKS_PER_CU", 4);
+    if (ctx->blocksPerCu == 0) ctx->blocksPerCu = 1;
+    ctx->forceGlobal = EnvU32("RT_FORCE_GLOBAL_TABLES", 0) != 0;
+    int rc = ctx->queue.Reserve(1);
+    if (rc == RT_OK) rc = ctx->counters.Reserve(2);
+    if (rc != RT_OK) {
+        delete ctx;
+        return rc;
+    }
+    // the LDS variant may need more than the default 64 KiB dynamic LDS limit in later rounds
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->scan.Release();
+    ctx->radius.Release();
+    ctx->mats.Release();
+    ctx->hdr.Release();
+    ctx->ldr.Release();
+    ctx->samples.Release();
+    ctx->queue.Release();
+    ctx->counters.Release();
+    for (auto& ev : ctx->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
+    delete ctx;
+}
+
+int rt_set_stream(rt_ctx* ctx, void* hip_stream) {
+    if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_set_stream: null ctx");
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->ownStream;
+    return RT_OK;
+}
+
+int rt_set_workspace_limit(rt_ctx* ctx, uint64_t bytes) {
+    if (!ctx || bytes < (1u << 20)) return Fail(RT_ERR_INVALID_ARG, "rt_set_workspace_limit: need >= 1 MiB");
+    ctx->workspaceLimit = bytes;
+    return RT_OK;
+}
+
+int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* materials, uint32_t n, const rt_camera* camera,
+                    const rt_light* sun, const rt_material* sky, float exposure_scale) {
+    if (!ctx || !spheres || !materials || !camera || !sun || !sky || n == 0)
+        return Fail(RT_ERR_INVALID_ARG, "rt_scene_upload: null pointer or empty scene");
+    RT_HIP(hipSetDevice(ctx->device));
+    int rc;
+    const uint32_t nPad = PaddedCount(n);
+    if ((rc = ctx->scan.Reserve(nPad)) != RT_OK) return rc;
+    if ((rc = ctx->radius.Reserve(n)) != RT_OK) return rc;
+    if ((rc = ctx->mats.Reserve(n)) != RT_OK) return rc;
+    // padding entries can never be hit: r*r = -1e30 makes the discriminant negative for any ray
+    std::vector<float4> scan(nPad, make_float4(0.f, 0.f, 0.f, -1e30f));
+    std::vector<float> rad(n);
+    for (uint32_t k = 0; k < n; ++k) {
+        // radius * radius is the float product Sphere::Intersect forms per call (ray-tracing.cpp:48)
+        scan[k] = make_float4(spheres[k].cx, spheres[k].cy, spheres[k].cz, spheres[k].r * spheres[k].r);
+        rad[k] = spheres[k].r;
+    }
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(hipMemcpy(ctx->scan.ptr, scan.data(), nPad * sizeof(float4), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->radius.ptr, rad.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->mats.ptr, materials, n * sizeof(rt_material), hipMemcpyHostToDevice));
+
+    rtd::TraceParams& b = ctx->base;
+    b = rtd::TraceParams{};
+    b.scan = ctx->scan.ptr;
+    b.radius = ctx->radius.ptr;
+    b.mats = ctx->mats.ptr;
+    b.n = n;
+    b.n_padded = nPad;
+    for (int k = 0; k < 3; ++k) {
+        b.cam_o[k] = camera->origin[k];
+        b.cam_x[k] = camera->x[k];
+        b.cam_y[k] = camera->y[k];
+        b.cam_oip[k] = camera->origin_image_plane[k];
+        b.sun_dir[k] = sun->direction[k];
+        b.sun_rad[k] = sun->luminance * sun->color[k];  // m_luminance * m_color, light.cpp:27
+        b.sky_emit[k] = sky->luminance * sky->rgb0[k];  // Emissive::Emit, material.cpp:172-175
+    }
+    b.aperture = camera->aperture;
+    b.focal = camera->focal_length;
+    b.exposure = exposure_scale;
+    ctx->n = n;
+    ctx->hasScene = true;
+    ctx->accumulated = 0;
+    return RT_OK;
+}
+
+int rt_clear(rt_ctx* ctx) {
+    if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_clear: null ctx");
+    ctx->accumulated = 0;
+    return RT_OK;
+}
+
+uint32_t rt_rowset_local_rows(rt_rowset rs) { return RowsetLocalRows(rs); }
+uint32_t rt_rowset_global_row(rt_rowset rs, uint32_t lr) {
+    const uint32_t lb = lr / rs.block_rows;
+    const uint32_t k = lr % rs.block_rows;
+    return rs.first_row + (lb * rs.nshards + rs.shard) * rs.block_rows + k;
+}
+
+int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1, uint32_t max_depth, uint64_t seed,
+              rt_stats* out_stats) {
+    if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_render: null ctx");
+    if (!ctx->hasScene) return Fail(RT_ERR_NO_SCENE, "rt_render: no scene uploaded");
+    if (W == 0 || H == 0 || s0 == 0 || s1 <= s0) return Fail(RT_ERR_INVALID_ARG, "rt_render: empty image or sample range");
+    const uint32_t rows = RowsetLocalRows(rs);
+    if (rows == 0 || (uint64_t)rs.first_row + rs.num_rows > H) return Fail(RT_ERR_INVALID_ARG, "rt_render: bad row set");
+    const uint64_t npix64 = (uint64_t)W * rows;
+    if (npix64 > (1ull << 31) || (uint64_t)W * H > 0xffffffffull) return Fail(RT_ERR_INVALID_ARG, "rt_render: image too large");
+    RT_HIP(hipSetDevice(ctx->device));
+    const uint32_t npix = (uint32_t)npix64;
+
+    const bool sameStrip = ctx->W == W && ctx->H == H && ctx->rows == rows && std::memcmp(&ctx->rs, &rs, sizeof(rs)) == 0;
+    if (s0 == 1 || ctx->accumulated == 0) {
+        if (s0 != 1) return Fail(RT_ERR_SEQUENCE, "rt_render: first call of an accumulation must start at s0 == 1");
+        int rc;
+        if ((rc = ctx->hdr.Reserve((size_t)npix * 3)) != RT_OK) return rc;
+        if ((rc = ctx->ldr.Reserve((size_t)npix * 3)) != RT_OK) return rc;
+        RT_HIP(hipMemsetAsync(ctx->hdr.ptr, 0, (size_t)npix * 3 * sizeof(float), ctx->stream));  // app.cpp:112-119
+        ctx->W = W;
+        ctx->H = H;
+        ctx->rows = rows;
+        ctx->rs = rs;
+        ctx->accumulated = 0;
+    } else if (!sameStrip || s0 != ctx->accumulated + 1) {
+        return Fail(RT_ERR_SEQUENCE, "rt_render: sample range or row set does not continue the accumulation");
+    }
+
+    // split [s0, s1) into passes whose sample buffer fits the workspace limit
+    const uint64_t bytesPerSpp = (uint64_t)npix * 12;
+    uint64_t sppMax = ctx->workspaceLimit / bytesPerSpp;
+    const uint64_t sppPathCap = ((1ull << 31) - 1) / npix;  // total_paths stays below 2^31
+    if (sppMax > sppPathCap) sppMax = sppPathCap;
+    if (sppMax == 0) return Fail(RT_ERR_OUT_OF_MEMORY, "rt_render: workspace limit below one sample per pixel");
+    const uint32_t sppTotal = s1 - s0;
+    const uint32_t sppPass = (uint32_t)(sppMax < sppTotal ? sppMax : sppTotal);
+    int rc;
+    if ((rc = ctx->samples.Reserve((size_t)npix * sppPass * 3)) != RT_OK) return rc;
+
+    RT_HIP(hipMemsetAsync(ctx->counters.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    float msTrace = 0.f, msAcc = 0.f;
+    uint32_t passes = 0;
+    for (uint32_t s = s0; s < s1; s += sppPass) {
+        const uint32_t spp = (s1 - s) < sppPass ? (s1 - s) : sppPass;
+        rtd::TraceParams tp = ctx->base;
+        tp.W = W;
+        tp.H = H;
+        tp.rs = rs;
+        tp.s0 = s;
+        tp.spp_pass = spp;
+        tp.total_paths = npix * spp;
+        tp.max_depth = max_depth;
+        tp.seed = seed;
+        tp.path_list = nullptr;
+        tp.samples = ctx->samples.ptr;
+        tp.trav_out = nullptr;
+        tp.queue_head = ctx->queue.ptr;
+        tp.counters = ctx->counters.ptr;
+        RT_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+        if ((rc = LaunchTrace(ctx, tp)) != RT_OK) return rc;
+        RT_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+        hipLaunchKernelGGL(rtd::rt_accumulate_kernel, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, ctx->samples.ptr, ctx->hdr.ptr,
+                           npix, spp);
+        RT_HIP(hipGetLastError());
+        RT_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+        RT_HIP(hipEventSynchronize(ctx->ev[2]));
+        float a = 0.f, b = 0.f;
+        RT_HIP(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+        RT_HIP(hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
+        msTrace += a;
+        msAcc += b;
+        ++passes;
+    }
+    ctx->accumulated += sppTotal;
+
+    if (out_stats) {
+        unsigned long long c[2] = {0, 0};
+        RT_HIP(hipMemcpy(c, ctx->counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
+        std::memset(out_stats, 0, sizeof(*out_stats));
+        out_stats->samples = (uint64_t)npix * sppTotal;
+        out_stats->traversals = c[0];
+        out_stats->segments = c[1];
+        out_stats->ms_render = msTrace;
+        out_stats->ms_accumulate = msAcc;
+        out_stats->ms_resolve = 0.0;
+        out_stats->local_rows = rows;
+        out_stats->passes = passes;
+    }
+    return RT_OK;
+}
+
+int rt_resolve(rt_ctx* ctx, uint32_t n_samples) {
+    if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_resolve: null ctx");
+    if (ctx->accumulated == 0) return Fail(RT_ERR_SEQUENCE, "rt_resolve: nothing accumulated");
+    RT_HIP(hipSetDevice(ctx->device));
+    const uint32_t n = n_samples ? n_samples : ctx->accumulated;
+    const uint32_t npix = ctx->W * ctx->rows;
+    RT_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(rtd::rt_resolve_kernel, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, ctx->hdr.ptr, ctx->ldr.ptr, npix, n);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    RT_HIP(hipEventSynchronize(ctx->ev[1]));
+    float ms = 0.f;
+    RT_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->lastResolveMs = ms;
+    return RT_OK;
+}
+
+double rt_last_resolve_ms(rt_ctx* ctx) { return ctx ? ctx->lastResolveMs : 0.0; }
+
+int rt_download(rt_ctx* ctx, float* hdr_rgb, uint8_t* ldr_rgb) {
+    if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_download: null ctx");
+    if (ctx->accumulated == 0) return Fail(RT_ERR_SEQUENCE, "rt_download: nothing rendered");
+    RT_HIP(hipSetDevice(ctx->device));
+    const size_t npix = (size_t)ctx->W * ctx->rows;
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    if (hdr_rgb) RT_HIP(hipMemcpy(hdr_rgb, ctx->hdr.ptr, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (ldr_rgb) RT_HIP(hipMemcpy(ldr_rgb, ctx->ldr.ptr, npix * 3, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_copy_to_device(rt_ctx* ctx, void* dev_hdr_rgb, void* dev_ldr_rgb) {
+    if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_copy_to_device: null ctx");
+    if (ctx->accumulated == 0) return Fail(RT_ERR_SEQUENCE, "rt_copy_to_device: nothing rendered");
+    RT_HIP(hipSetDevice(ctx->device));
+    const size_t npix = (size_t)ctx->W * ctx->rows;
+    if (dev_hdr_rgb) RT_HIP(hipMemcpyAsync(dev_hdr_rgb, ctx->hdr.ptr, npix * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    if (dev_ldr_rgb) RT_HIP(hipMemcpyAsync(dev_ldr_rgb, ctx->ldr.ptr, npix * 3, hipMemcpyDeviceToDevice, ctx->stream));
+    return RT_OK;
+}
+
+int rt_synchronize(rt_ctx* ctx) {
+    if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_synchronize: null ctx");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------------ unit entries
+int rt_unit_halton(rt_ctx* ctx, const uint32_t* index, uint32_t base, uint32_t n, float* out) {
+    if (!ctx || !index || !out || base < 2) return Fail(RT_ERR_INVALID_ARG, "rt_unit_halton: invalid argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    TmpDev<uint32_t> dIdx;
+    TmpDev<float> dOut;
+    RT_HIP(dIdx.Alloc(n));
+    RT_HIP(dOut.Alloc(n));
+    RT_HIP(hipMemcpy(dIdx.p, index, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rtd::k_unit_halton, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dIdx.p, base, n, dOut.p);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(hipMemcpy(out, dOut.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_unit_math(rt_ctx* ctx, uint32_t op, const float* x, const float* y, uint32_t n, float* out) {
+    if (!ctx || !x || !out || op > 3) return Fail(RT_ERR_INVALID_ARG, "rt_unit_math: invalid argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    TmpDev<float> dX, dY, dOut;
+    RT_HIP(dX.Alloc(n));
+    RT_HIP(dY.Alloc(n));
+    RT_HIP(dOut.Alloc(n));
+    RT_HIP(hipMemcpy(dX.p, x, n * sizeof(float), hipMemcpyHostToDevice));
+    if (y) RT_HIP(hipMemcpy(dY.p, y, n * sizeof(float), hipMemcpyHostToDevice));
+    else RT_HIP(hipMemset(dY.p, 0, n * sizeof(float)));
+    hipLaunchKernelGGL(rtd::k_unit_math, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, op, dX.p, dY.p, n, dOut.p);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(hipMemcpy(out, dOut.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_unit_primary_rays(rt_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* ijs, uint32_t n, float* out_rays) {
+    if (!ctx || !ijs || !out_rays || W == 0 || H == 0) return Fail(RT_ERR_INVALID_ARG, "rt_unit_primary_rays: invalid argument");
+    if (!ctx->hasScene) return Fail(RT_ERR_NO_SCENE, "rt_unit_primary_rays: no scene uploaded");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    TmpDev<uint32_t> dIjs;
+    TmpDev<float> dOut;
+    RT_HIP(dIjs.Alloc((size_t)n * 3));
+    RT_HIP(dOut.Alloc((size_t)n * 6));
+    RT_HIP(hipMemcpy(dIjs.p, ijs, (size_t)n * 3 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    rtd::TraceParams tp = ctx->base;
+    tp.W = W;
+    tp.H = H;
+    hipLaunchKernelGGL(rtd::k_unit_primary, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, tp, dIjs.p, n, dOut.p);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(hipMemcpy(out_rays, dOut.p, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_unit_closest_hit(rt_ctx* ctx, const float* rays, uint32_t n, float* out_hits) {
+    if (!ctx || !rays || !out_hits) return Fail(RT_ERR_INVALID_ARG, "rt_unit_closest_hit: invalid argument");
+    if (!ctx->hasScene) return Fail(RT_ERR_NO_SCENE, "rt_unit_closest_hit: no scene uploaded");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    TmpDev<float> dRays, dOut;
+    RT_HIP(dRays.Alloc((size_t)n * 6));
+    RT_HIP(dOut.Alloc((size_t)n * 10));
+    RT_HIP(hipMemcpy(dRays.p, rays, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rtd::k_unit_closest, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->base, dRays.p, n, dOut.p);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(hipMemcpy(out_hits, dOut.p, (size_t)n * 10 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_unit_trace(rt_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* ijs, uint32_t n, uint32_t max_depth, uint64_t seed,
+                  float* out_rgb, uint32_t* out_traversals) {
+    if (!ctx || !ijs || !out_rgb || W == 0 || H == 0) return Fail(RT_ERR_INVALID_ARG, "rt_unit_trace: invalid argument");
+    if (!ctx->hasScene) return Fail(RT_ERR_NO_SCENE, "rt_unit_trace: no scene uploaded");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    TmpDev<uint32_t> dIjs, dTrav;
+    TmpDev<float> dOut;
+    RT_HIP(dIjs.Alloc((size_t)n * 3));
+    RT_HIP(dTrav.Alloc(n));
+    RT_HIP(dOut.Alloc((size_t)n * 3));
+    RT_HIP(hipMemcpy(dIjs.p, ijs, (size_t)n * 3 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    RT_HIP(hipMemsetAsync(ctx->counters.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    rtd::TraceParams tp = ctx->base;
+    tp.W = W;
+    tp.H = H;
+    tp.rs = rt_rowset{0, H, H, 0, 1};
+    tp.s0 = 1;
+    tp.spp_pass = 1;
+    tp.total_paths = n;
+    tp.max_depth = max_depth;
+    tp.seed = seed;
+    tp.path_list = dIjs.p;
+    tp.samples = dOut.p;
+    tp.trav_out = dTrav.p;
+    tp.queue_head = ctx->queue.ptr;
+    tp.counters = ctx->counters.ptr;
+    int rc = LaunchTrace(ctx, tp);
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(hipMemcpy(out_rgb, dOut.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_traversals) RT_HIP(hipMemcpy(out_traversals, dTrav.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+}  // extern "C"

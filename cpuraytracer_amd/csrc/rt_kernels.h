@@ -1,0 +1,544 @@
+// rt_kernels.h — HIP kernels of the render-loop hot path for MI355X (gfx950 / CDNA4).
+//
+// What runs where (reference file:line -> kernel):
+//   GenerateRays            spheres-app.cpp:132-161  -> gen_primary_ray()           (in-register, never materialised)
+//   for_each(par) trace     spheres-app.cpp:177-184  -> rt_trace_kernel             (persistent-threads megakernel)
+//   GetHitColor recursion   spheres-app.cpp:238-257  -> per-lane state machine in rt_trace_kernel
+//   BvhNode/Sphere::Intersect ray-tracing.cpp:42-84,174-214 -> scan_list()          (LDS list scan, closest hit)
+//   Material::Scatter x3    material.cpp:20-164      -> scatter_and_shade()
+//   DirectionalLight::Shade light.cpp:11-42          -> scatter_and_shade() + the shadow scan
+//   hdr[id] += L*exposure   spheres-app.cpp:182-183  -> rt_accumulate_kernel        (ordered in s)
+//   tonemap transform(par)  spheres-app.cpp:196-214  -> rt_resolve_kernel
+//
+// Design (DESIGN.md has the long form):
+//   * one work-item per (pixel, sample) PATH; a wave keeps 64 paths in flight and refills finished
+//     lanes from a global queue by ballot + prefix count, so lanes stay full despite path lengths
+//     of 1..102 list scans;
+//   * a lane is always in one of two states, "needs closest-hit scan" or "needs shadow scan"; both
+//     run the SAME list scan, so every wave iteration is one scan with all 64 lanes doing useful
+//     intersection arithmetic (the shade value is computed before the shadow scan and added after
+//     it only if the sun is visible — same numbers as the reference's order, no state to carry);
+//   * the sphere list (cx,cy,cz,r^2), radii and material table are staged into LDS once per
+//     workgroup; the scan reads one sphere per ds_read_b128 at a wave-uniform address (broadcast).
+//     Measured on MI355X (profiles/r01_valu_rate2_microbench.jsonl): a VALU op with an SGPR source
+//     issues at half rate, so sphere data must arrive in VGPRs — LDS broadcast, not s_load;
+//   * xoshiro128** state in 4 VGPRs per lane; no MFMA (branchy scalar FP32, 3-term dot products);
+//   * per-path results go to an HBM sample buffer [pixel][s] (12 B each) and are summed in
+//     increasing s by rt_accumulate_kernel: the reference's summation order, bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_api.h"
+#include "rt_device_math.h"
+
+namespace rtd {
+
+constexpr int kWaveSize = 64;
+constexpr uint32_t kQueueBlock = 256;  // paths a wave takes from the global queue per atomic
+
+struct TraceParams {
+    // scene
+    const float4* scan;        // [n_padded] cx, cy, cz, r*r (padding: never-hit entries)
+    const float* radius;       // [n]
+    const rt_material* mats;   // [n]
+    uint32_t n;
+    uint32_t n_padded;         // roundup(n, 8) + 4
+    float cam_o[3], cam_x[3], cam_y[3], cam_oip[3];
+    float aperture, focal;
+    float sun_dir[3], sun_rad[3];  // sun_rad = luminance * colour (light.cpp:27, left factor)
+    float sky_emit[3];             // luminance * colour (material.cpp:172-175)
+    float exposure;
+    // work
+    uint32_t W, H;
+    rt_rowset rs;
+    uint32_t s0;          // first sample index of this pass (1-based)
+    uint32_t spp_pass;    // samples per pixel in this pass
+    uint32_t total_paths; // W * local_rows * spp_pass, or the path-list length
+    uint32_t max_depth;
+    uint64_t seed;
+    const uint32_t* path_list;  // optional explicit (i, j, s) triples (unit tests)
+    float* samples;             // [total_paths][3] radiance * exposure
+    uint32_t* trav_out;         // optional per-path traversal counts
+    uint32_t* queue_head;       // global work counter, zeroed before launch
+    unsigned long long* counters;  // [0] traversals, [1] segments
+};
+
+// --------------------------------------------------------------------------- row sets
+RT_DEV uint32_t rowset_global_row(const rt_rowset& rs, uint32_t lr) {
+    const uint32_t lb = lr / rs.block_rows;
+    const uint32_t k = lr - lb * rs.block_rows;
+    return rs.first_row + (lb * rs.nshards + rs.shard) * rs.block_rows + k;
+}
+
+// ------------------------------------------------------------------ primary rays (A1, A2)
+// SpheresApp::GenerateRays (spheres-app.cpp:132-161) + Camera::GetRay (camera.cpp:30-48) for one
+// (i, j, s).  jitter = Halton2D(s;2,3); lens = HaltonSampleDisk(s+i+j;4,5).
+RT_DEV void gen_primary_ray(const TraceParams& p, uint32_t i, uint32_t j, uint32_t s, V3& origin, V3& dir) {
+    const float xsize = (float)p.W;
+    const float ysize = (float)p.H;
+    const float jx = halton(s, 2);
+    const float jy = halton(s, 3);
+    const float uvx = ((float)(int)i + jx) / xsize;
+    const float uvy = ((float)(int)j + jy) / ysize;
+    const uint32_t li = s + i + j;
+    const float theta = (2.f * 3.141592654f) * halton(li, 4);  // quasi-random.cpp:54
+    const float r = halton(li, 5);
+    double sn, cs;
+    sincos_f64(theta, sn, cs);
+    const float lensx = r * (float)cs;
+    const float lensy = r * (float)sn;
+
+    const V3 camO = v3(p.cam_o[0], p.cam_o[1], p.cam_o[2]);
+    const V3 mx = v3(p.cam_x[0], p.cam_x[1], p.cam_x[2]);
+    const V3 my = v3(p.cam_y[0], p.cam_y[1], p.cam_y[2]);
+    const V3 oip = v3(p.cam_oip[0], p.cam_oip[1], p.cam_oip[2]);
+
+    const float ndcx = 2.f * uvx - 1.f;
+    const float ndcy = -2.f * uvy + 1.f;
+    const V3 pp = (oip + ndcx * mx) + ndcy * my;
+    const V3 focalPoint = camO + p.focal * normalize3(pp - camO);
+    const float rdx = (0.5f * p.aperture) * lensx;
+    const float rdy = (0.5f * p.aperture) * lensy;
+    origin = (camO + rdx * mx) + rdy * my;
+    dir = normalize3(focalPoint - origin);
+}
+
+// ---------------------------------------------------------------------- list scan (A4, A6)
+// Closest acceptable root over the whole list; equal t keeps the lower index.  Per sphere:
+// Sphere::Intersect's arithmetic (ray-tracing.cpp:44-50) = 17 f32 VALU ops in VOP2 form with all
+// operands in VGPRs.  Spheres are taken four at a time: the next group's four ds_read_b128 are
+// issued before the current group's arithmetic (software prefetch — the per-sphere branch would
+// otherwise pin every read right in front of its use), and ONE compare + branch per group guards
+// the rarely needed sqrt/div root evaluation: disc > 0 for some sphere of the group implies the
+// AND of the four discriminants' bit patterns has a clear sign bit (a conservative pre-filter; the
+// exact `disc > 0` is re-tested per sphere inside).  The table is padded by the host to a multiple
+// of eight plus one group with never-hit entries (r*r = -1e30 => disc < 0).
+constexpr uint32_t kScanGroup = 4;
+
+RT_DEV void root_test(float disc, float b, float a, uint32_t i, float& tmin, int& idx) {
+    if (disc > 0.f) {  // ray-tracing.cpp:54
+        const float sq = __builtin_sqrtf(disc);
+        float t = (-b - sq) / a;                      // :56
+        if (!(t > 0.001f)) t = (-b + sq) / a;         // :58, :69-71 (bias 0.001, :52)
+        if (t > 0.001f && t < tmin) {
+            tmin = t;
+            idx = (int)i;
+        }
+    }
+}
+
+// One group: discriminants of four spheres, then the guarded root evaluation.
+RT_DEV void scan_group(const float4 S0, const float4 S1, const float4 S2, const float4 S3, uint32_t i, V3 o, V3 d, float a, float& tmin,
+                       int& idx) {
+    float b0, b1, b2, b3, e0, e1, e2, e3;
+#define RT_DISC(S, B, E)                                               \
+    {                                                                  \
+        const float ocx = o.x - S.x;                                   \
+        const float ocy = o.y - S.y;                                   \
+        const float ocz = o.z - S.z;                                   \
+        B = (ocx * d.x + ocy * d.y) + ocz * d.z;                       \
+        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;  \
+        E = B * B - a * cc;                                            \
+    }
+    RT_DISC(S0, b0, e0)
+    RT_DISC(S1, b1, e1)
+    RT_DISC(S2, b2, e2)
+    RT_DISC(S3, b3, e3)
+#undef RT_DISC
+    const int signs = __float_as_int(e0) & __float_as_int(e1) & __float_as_int(e2) & __float_as_int(e3);
+    if (__builtin_expect(signs >= 0, 0)) {
+        root_test(e0, b0, a, i + 0, tmin, idx);
+        root_test(e1, b1, a, i + 1, tmin, idx);
+        root_test(e2, b2, a, i + 2, tmin, idx);
+        root_test(e3, b3, a, i + 3, tmin, idx);
+    }
+}
+
+// nPadded = roundup(n, 8) + 4: two groups per iteration on ping-pong register sets (no copies);
+// the final group is padding and is only ever prefetched.
+RT_DEV void scan_list(const float4* __restrict__ tab, uint32_t nPadded, V3 o, V3 d, float& tmin, int& idx) {
+    const float a = dot3(d, d);
+    tmin = __builtin_inff();
+    idx = -1;
+    float4 A0 = tab[0], A1 = tab[1], A2 = tab[2], A3 = tab[3];
+    for (uint32_t i = 0; i + kScanGroup < nPadded; i += 2 * kScanGroup) {
+        const float4 B0 = tab[i + 4], B1 = tab[i + 5], B2 = tab[i + 6], B3 = tab[i + 7];
+        scan_group(A0, A1, A2, A3, i, o, d, a, tmin, idx);
+        A0 = tab[i + 8]; A1 = tab[i + 9]; A2 = tab[i + 10]; A3 = tab[i + 11];
+        scan_group(B0, B1, B2, B3, i + 4, o, d, a, tmin, idx);
+    }
+}
+
+// --------------------------------------------------------- textures (A14), getters (A13)
+// Material record held in registers (loaded as three 16-byte reads; a by-value struct copy would
+// be demoted to scratch/LDS by the compiler).
+struct Mat {
+    uint32_t type, tex_type;
+    float smoothness, ior, tiling;
+    float rgb0[3], rgb1[3];
+    float luminance;
+};
+RT_DEV Mat load_material(const rt_material* tab, int idx) {
+    const float4* q = reinterpret_cast<const float4*>(tab) + (size_t)idx * 3;
+    const float4 a = q[0], b = q[1], c = q[2];
+    Mat m;
+    m.type = __float_as_uint(a.x); m.tex_type = __float_as_uint(a.y); m.smoothness = a.z; m.ior = a.w;
+    m.tiling = b.x; m.rgb0[0] = b.y; m.rgb0[1] = b.z; m.rgb0[2] = b.w;
+    m.rgb1[0] = c.x; m.rgb1[1] = c.y; m.rgb1[2] = c.z; m.luminance = c.w;
+    return m;
+}
+RT_DEV V3 eval_texture(const Mat& m, float u, float v) {
+    if (m.tex_type == RT_TEX_CHECKER) {  // texture.cpp:20-33
+        const int iu = (int)(m.tiling * u);
+        const int iv = (int)(m.tiling * v);
+        if (iu % 2 == iv % 2) return v3(m.rgb0[0], m.rgb0[1], m.rgb0[2]);
+        return v3(m.rgb1[0], m.rgb1[1], m.rgb1[2]);
+    }
+    return v3(m.rgb0[0], m.rgb0[1], m.rgb0[2]);  // texture.cpp:8-11
+}
+
+// ------------------------------------------------- hit processing (A8, A10-A13, A15)
+// Runs Material::Scatter (draws first, material.cpp) then DirectionalLight::Shade's unoccluded
+// value (light.cpp:21-40).  Outputs: scattered flag, attenuation, scattered direction, local =
+// Emit + Shade assuming the sun is visible (the caller adds it only if the shadow scan misses).
+RT_DEV bool scatter_and_shade(const TraceParams& p, const Mat& m, V3 rd, V3 pos, V3 nrm, Rng& rng, V3& atten, V3& outDir,
+                              V3& local) {
+    const float uvx = 0.5f * nrm.x + 0.5f;  // Sphere::ComputeUV, ray-tracing.cpp:26-40
+    const float uvy = 0.5f * nrm.z + 0.5f;
+    const V3 tex = eval_texture(m, uvx, uvy);
+    bool scattered = false;
+    atten = v3(1.f, 1.f, 1.f);
+    outDir = v3(0.f, 0.f, 0.f);
+
+    if (m.type == RT_MAT_DIELECTRIC_TRANSPARENT) {  // material.cpp:111-164
+        const float dn = dot3(rd, nrm);
+        V3 outwardNormal;
+        float niOverNt, cosI;
+        if (dn > 0.f) {
+            outwardNormal = -nrm;
+            niOverNt = m.ior;
+            cosI = dot3(rd, nrm);
+        } else {
+            outwardNormal = nrm;
+            niOverNt = 1.0f / m.ior;  // XMVectorReciprocalEst restated exact
+            cosI = dot3(rd, -nrm);
+        }
+        const V3 refr = refract3(rd, outwardNormal, niOverNt);
+        const bool canRefract = (refr.x != 0.f) || (refr.y != 0.f) || (refr.z != 0.f);
+        const float prob = canRefract ? fresnel_term(cosI, m.ior) : 1.f;
+        const float u = rng_uniform(rng);
+        if (prob > u) outDir = normalize3(reflect3(rd, nrm));
+        else outDir = normalize3(refr);
+        scattered = true;
+    } else if (m.type == RT_MAT_METAL) {  // material.cpp:72-103
+        const float ndv = dot3(-rd, nrm);
+        if (ndv > 0.f) {
+            // The 4-lane coin (XMVectorGreaterR + AnyTrue) is always true: lane w of f0 is the
+            // colour's alpha = 1, so R.w = 1 > u.  The draw is still consumed (material.cpp:82).
+            (void)rng_uniform(rng);
+            atten = tex;
+            outDir = normalize3(reflect3(rd, nrm));
+            scattered = true;
+        }
+    } else if (m.type == RT_MAT_DIELECTRIC_OPAQUE) {  // material.cpp:20-65
+        const float ndv = dot3(-rd, nrm);
+        if (ndv > 0.f) {
+            const float nDotV = sat1(ndv);
+            const float refl = 0.04f + (1.f - 0.04f) * rt_powf(1.f - nDotV, 5.f);
+            const float u = rng_uniform(rng);
+            if (refl > u) {
+                atten = v3(1.f, 1.f, 1.f);
+                outDir = normalize3(reflect3(rd, nrm));
+            } else {
+                atten = tex;
+                const float u1 = rng_uniform(rng);  // HaltonSampleHemisphere's two dimensions
+                const float u2 = rng_uniform(rng);
+                const float r = __builtin_sqrtf(1.f - u1 * u1);  // quasi-random.cpp:41
+                const float phi = (2.f * 3.141592654f) * u2;
+                double sn, cs;
+                sincos_f64(phi, sn, cs);
+                const float hx = r * (float)cs, hy = r * (float)sn, hz = u1;
+                const V3 b3 = nrm;
+                const V3 up = __builtin_fabsf(nrm.x) < 0.5f ? v3(1.f, 0.f, 0.f) : v3(0.f, 1.f, 0.f);
+                const V3 b1 = cross3(up, b3);
+                const V3 b2 = cross3(b3, b1);
+                const V3 sd = (hx * b1 + hy * b2) + hz * b3;
+                outDir = normalize3(sd);
+            }
+            scattered = true;
+        }
+    }
+
+    // Material getters (material.h:26-29,42-45,59-62,76-79)
+    V3 albedo = v3(0.f, 0.f, 0.f), f0 = v3(0.04f, 0.04f, 0.04f);
+    if (m.type == RT_MAT_DIELECTRIC_OPAQUE) albedo = tex;
+    else if (m.type == RT_MAT_METAL) f0 = tex;
+    else if (m.type == RT_MAT_EMISSIVE) f0 = v3(0.f, 0.f, 0.f);
+    const float smooth = (m.type == RT_MAT_EMISSIVE) ? 0.f : m.smoothness;
+
+    // DirectionalLight::Shade, light.cpp:21-40 (viewOrigin is always the camera origin, spheres-app.cpp:250)
+    const V3 L = v3(p.sun_dir[0], p.sun_dir[1], p.sun_dir[2]);
+    const float nDotL = sat1(dot3(nrm, L));
+    const V3 radianceIn = v3(p.sun_rad[0] * nDotL, p.sun_rad[1] * nDotL, p.sun_rad[2] * nDotL);
+    const V3 viewDir = normalize3(v3(p.cam_o[0], p.cam_o[1], p.cam_o[2]) - pos);
+    const V3 halfVector = normalize3(L + viewDir);
+    const float nDotH = sat1(dot3(nrm, halfVector));
+    const float nDotV2 = sat1(dot3(viewDir, nrm));
+    const float p5 = rt_powf(1.f - nDotV2, 5.f);
+    const float ps = rt_powf(nDotH, smooth);
+    const V3 one = v3(1.f, 1.f, 1.f);
+    const V3 reflectance = f0 + (one - f0) * p5;
+    const V3 spec = ((reflectance * 0.125f) * (smooth + 8.f)) * ps;
+    const V3 shade = radianceIn * (albedo + spec);
+    // Emit (0 for every scene material; Emissive spheres would emit luminance*colour) + Shade
+    V3 emit = v3(0.f, 0.f, 0.f);
+    if (m.type == RT_MAT_EMISSIVE) emit = m.luminance * tex;
+    local = emit + shade;
+    return scattered;
+}
+
+// lanes below mine that are set in mask
+RT_DEV uint32_t prefix_count(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+enum : uint32_t { kIdle = 0u, kNeedClosest = 1u, kNeedShadow = 2u };
+
+// ============================================================================ megakernel
+// Persistent threads: every wave loops { refill idle lanes from the queue; one list scan for all
+// lanes; per-lane state transition } until the queue is empty and all its lanes are idle.  Waves
+// never synchronise with each other after the LDS staging barrier, and every wave's loop ends when
+// the (bounded, monotonically consumed) queue is exhausted and its at most 64 paths of at most
+// max_depth+1 segments have finished.
+template <bool kLds>
+__global__ void __launch_bounds__(256) rt_trace_kernel(const TraceParams p) {
+    extern __shared__ float4 smem[];
+    const float4* scanTab = p.scan;
+    const float* radTab = p.radius;
+    const rt_material* matTab = p.mats;
+    if (kLds) {
+        // LDS image: [n_padded] float4 scan | [n] rt_material (48 B = 3 float4) | [n] float radius
+        float4* ldsScan = smem;
+        float4* ldsMat = smem + p.n_padded;
+        float* ldsRad = reinterpret_cast<float*>(smem + (size_t)p.n_padded + (size_t)p.n * 3);
+        const float4* gMat = reinterpret_cast<const float4*>(p.mats);
+        for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) ldsScan[k] = p.scan[k];
+        for (uint32_t k = threadIdx.x; k < p.n * 3; k += blockDim.x) ldsMat[k] = gMat[k];
+        for (uint32_t k = threadIdx.x; k < p.n; k += blockDim.x) ldsRad[k] = p.radius[k];
+        __syncthreads();
+        scanTab = ldsScan;
+        radTab = ldsRad;
+        matTab = reinterpret_cast<const rt_material*>(ldsMat);
+    }
+
+    const uint32_t lane = threadIdx.x & (kWaveSize - 1);
+    const V3 sunDir = v3(p.sun_dir[0], p.sun_dir[1], p.sun_dir[2]);
+
+    // per-lane path state
+    V3 ro = v3(0.f, 0.f, 0.f), rd = v3(0.f, 0.f, 1.f);  // current ray
+    V3 thr = v3(1.f, 1.f, 1.f), rad = v3(0.f, 0.f, 0.f);
+    V3 pend = v3(0.f, 0.f, 0.f), nextDir = v3(0.f, 0.f, 0.f);
+    Rng rng{1u, 0u, 0u, 0u};
+    uint32_t q = 0, depth = 0, state = kIdle, pathTrav = 0;
+    bool contAfterShadow = false;
+    uint32_t nTrav = 0, nSeg = 0;
+
+    // wave-uniform queue window
+    uint32_t blkNext = 0, blkEnd = 0;
+    bool queueEmpty = false;
+
+    for (;;) {
+        // ------------------------------------------------ refill idle lanes (ballot + prefix)
+        uint64_t idleMask = __ballot(state == kIdle);
+        while (idleMask != 0ull && !queueEmpty) {
+            if (blkNext == blkEnd) {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(p.queue_head, kQueueBlock);
+                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                blkNext = b < p.total_paths ? b : p.total_paths;
+                blkEnd = (b + kQueueBlock) < p.total_paths ? (b + kQueueBlock) : p.total_paths;
+                if (b >= p.total_paths) {
+                    queueEmpty = true;
+                    break;
+                }
+            }
+            const uint32_t avail = blkEnd - blkNext;
+            const uint32_t want = (uint32_t)__popcll(idleMask);
+            const uint32_t rank = prefix_count(idleMask);
+            if (state == kIdle && rank < avail) {
+                q = blkNext + rank;
+                uint32_t i, j, s;
+                if (p.path_list) {
+                    i = p.path_list[3 * q];
+                    j = p.path_list[3 * q + 1];
+                    s = p.path_list[3 * q + 2];
+                } else {
+                    const uint32_t pl = q / p.spp_pass;
+                    s = p.s0 + (q - pl * p.spp_pass);
+                    const uint32_t lr = pl / p.W;
+                    i = pl - lr * p.W;
+                    j = rowset_global_row(p.rs, lr);
+                }
+                rng = rng_seed(p.seed, j * p.W + i, s);
+                gen_primary_ray(p, i, j, s, ro, rd);
+                thr = v3(1.f, 1.f, 1.f);
+                rad = v3(0.f, 0.f, 0.f);
+                depth = 0;
+                pathTrav = 0;
+                state = kNeedClosest;
+            }
+            blkNext += want < avail ? want : avail;
+            idleMask = __ballot(state == kIdle);
+        }
+        if (__ballot(state != kIdle) == 0ull) break;  // queue empty and every lane drained
+
+        // ------------------------------------------------ one list scan for every live lane
+        float tmin = 0.f;
+        int idx = -1;
+        if (state != kIdle) {
+            scan_list(scanTab, p.n_padded, ro, rd, tmin, idx);
+            ++nTrav;
+            ++pathTrav;
+        }
+
+        // ------------------------------------------------ state transitions
+        bool finished = false;
+        if (state == kNeedClosest) {
+            ++nSeg;
+            if (idx < 0) {
+                // miss: sky Emissive::Emit (spheres-app.cpp:255)
+                const V3 sky = v3(p.sky_emit[0], p.sky_emit[1], p.sky_emit[2]);
+                rad = rad + thr * sky;
+                finished = true;
+            } else {
+                const float4 S = scanTab[idx];
+                const float radius = radTab[idx];
+                const Mat m = load_material(matTab, idx);
+                const V3 center = v3(S.x, S.y, S.z);
+                const V3 pos = tmin * rd + ro;          // XMVectorMultiplyAdd(t, dir, origin), ray-tracing.cpp:57
+                const V3 nrm = (pos - center) / radius;  // ray-tracing.cpp:58
+                V3 atten, local;
+                const bool scattered = scatter_and_shade(p, m, rd, pos, nrm, rng, atten, nextDir, local);
+                pend = thr * local;
+                contAfterShadow = (depth < p.max_depth) && scattered;  // spheres-app.cpp:247
+                thr = thr * atten;
+                ro = pos;  // shadow ray and scattered ray both start at hit.pos
+                rd = sunDir;
+                state = kNeedShadow;
+            }
+        } else if (state == kNeedShadow) {
+            if (idx < 0) rad = rad + pend;  // sun visible: radiance += throughput * (Emit + Shade)
+            if (contAfterShadow) {
+                rd = nextDir;
+                ++depth;
+                state = kNeedClosest;
+            } else {
+                finished = true;
+            }
+        }
+        if (finished) {
+            float* out = p.samples + (size_t)q * 3;
+            out[0] = rad.x * p.exposure;  // GetHitColor * exposureAdjustment, spheres-app.cpp:183
+            out[1] = rad.y * p.exposure;
+            out[2] = rad.z * p.exposure;
+            if (p.trav_out) p.trav_out[q] = pathTrav;
+            state = kIdle;
+        }
+    }
+
+    // counters: wave reduce, one atomic pair per wave
+    unsigned long long t = nTrav, s = nSeg;
+    for (int off = 32; off > 0; off >>= 1) {
+        t += __shfl_down(t, off);
+        s += __shfl_down(s, off);
+    }
+    if (lane == 0) {
+        atomicAdd(&p.counters[0], t);
+        atomicAdd(&p.counters[1], s);
+    }
+}
+
+// ============================================================== ordered accumulation (A16)
+// hdr[pixel] += sample(pixel, s) for s = s0 .. s0+spp-1 in that order (spheres-app.cpp:182-183).
+__global__ void __launch_bounds__(256) rt_accumulate_kernel(const float* __restrict__ samples, float* __restrict__ hdr, uint32_t npix,
+                                                            uint32_t spp) {
+    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= npix) return;
+    float r = hdr[3 * (size_t)pix], g = hdr[3 * (size_t)pix + 1], b = hdr[3 * (size_t)pix + 2];
+    const float* sp = samples + (size_t)pix * spp * 3;
+    for (uint32_t s = 0; s < spp; ++s) {
+        r += sp[3 * s];
+        g += sp[3 * s + 1];
+        b += sp[3 * s + 2];
+    }
+    hdr[3 * (size_t)pix] = r;
+    hdr[3 * (size_t)pix + 1] = g;
+    hdr[3 * (size_t)pix + 2] = b;
+}
+
+// ====================================================================== resolve (A17)
+// hdr / n, ACES fit, gamma 1/2.2, XMStoreColor (spheres-app.cpp:186-214); output R,G,B bytes.
+RT_DEV float tonemap_channel(float h, float n) {
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    float color = h / n;
+    color = sat1((color * (a * color + b)) / (color * (c * color + d) + e));
+    color = rt_powf(color, 1 / 2.2f);
+    return color;
+}
+__global__ void __launch_bounds__(256) rt_resolve_kernel(const float* __restrict__ hdr, uint8_t* __restrict__ ldr, uint32_t npix,
+                                                         uint32_t nSamples) {
+    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= npix) return;
+    const float n = (float)nSamples;
+    for (int ch = 0; ch < 3; ++ch) ldr[3 * (size_t)pix + ch] = (uint8_t)rne_u8(tonemap_channel(hdr[3 * (size_t)pix + ch], n));
+}
+
+// ================================================================== unit-test kernels
+__global__ void k_unit_halton(const uint32_t* index, uint32_t base, uint32_t n, float* out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = halton(index[k], base);
+}
+__global__ void k_unit_math(uint32_t op, const float* x, const float* y, uint32_t n, float* out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    float r = 0.f;
+    if (op == 0) r = rt_sinf(x[k]);
+    else if (op == 1) r = rt_cosf(x[k]);
+    else if (op == 2) r = rt_powf(x[k], y[k]);
+    else if (op == 3) r = rt_tanf(x[k]);
+    out[k] = r;
+}
+__global__ void k_unit_primary(const TraceParams p, const uint32_t* ijs, uint32_t n, float* out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    V3 o, d;
+    gen_primary_ray(p, ijs[3 * k], ijs[3 * k + 1], ijs[3 * k + 2], o, d);
+    float* w = out + 6 * (size_t)k;
+    w[0] = o.x; w[1] = o.y; w[2] = o.z; w[3] = d.x; w[4] = d.y; w[5] = d.z;
+}
+__global__ void k_unit_closest(const TraceParams p, const float* rays, uint32_t n, float* out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float* r = rays + 6 * (size_t)k;
+    const V3 o = v3(r[0], r[1], r[2]), d = v3(r[3], r[4], r[5]);
+    float tmin;
+    int idx;
+    scan_list(p.scan, p.n_padded, o, d, tmin, idx);
+    float* w = out + 10 * (size_t)k;
+    for (int c = 0; c < 10; ++c) w[c] = 0.f;
+    w[1] = __int_as_float(idx);
+    if (idx >= 0) {
+        const float4 S = p.scan[idx];
+        const V3 pos = tmin * d + o;
+        const V3 nrm = (pos - v3(S.x, S.y, S.z)) / p.radius[idx];
+        w[0] = tmin;
+        w[2] = pos.x; w[3] = pos.y; w[4] = pos.z;
+        w[5] = nrm.x; w[6] = nrm.y; w[7] = nrm.z;
+        w[8] = 0.5f * nrm.x + 0.5f;
+        w[9] = 0.5f * nrm.z + 0.5f;
+    }
+}
+
+}  // namespace rtd

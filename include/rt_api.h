@@ -161,6 +161,8 @@ int rt_clear(rt_ctx* ctx);
 /* Replaces the transform(par) tonemap (spheres-app.cpp:186-214): hdr / n_samples,
  * ACES fit, gamma 1/2.2, XMStoreColor.  n_samples == 0 uses the accumulated count. */
 int rt_resolve(rt_ctx* ctx, uint32_t n_samples);
+/* HIP-event time of the last rt_resolve kernel, milliseconds. */
+double rt_last_resolve_ms(rt_ctx* ctx);
 
 /* Copy the strip to host.  hdr_rgb: W*local_rows*3 floats; ldr_rgb: W*local_rows*3
  * bytes (R,G,B of the XMCOLOR).  Either pointer may be NULL. */

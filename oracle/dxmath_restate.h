@@ -297,7 +297,7 @@ inline uint64_t f64_bits(double d) { uint64_t b; std::memcpy(&b, &d, 8); return 
 // pow(x,y) = 2^(y*log2 x), x >= 0.
 inline float rt_powf(float xf, float yf) {
     if (yf == 0.f) return 1.f;
-    if (xf == 0.f) return 0.f;
+    if (!(xf > 0.f)) return 0.f;  // zero (and, off-domain, negative/NaN) base
     if (xf == 1.f) return 1.f;
     const double x = (double)xf;
     const uint64_t bits = f64_bits(x);
