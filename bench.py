@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the render-loop hot path on MI355X.
+
+Metric (BASELINE.json): Msamples/s = W*H*spp / render-seconds on the RTIOW-style cover scene
+(488 spheres, all materials), 1200x800, depth 50.  A "step" is one pass of the hot path over one
+batch: ray generation + trace + ordered accumulate + tonemap of the whole image at spp samples per
+pixel (the reference's DrawBitmap bracket, spheres-app.cpp:20-26, minus its Direct2D blit).
+Inputs (scene tables) are resident in HBM before the timed region starts.
+
+N = 1 : spp = 128                       (BASELINE.json configs[1])
+N > 1 : spp = 128 * N, image rows sharded cyclically across ranks, one RCCL gather of the strips
+        to rank 0 per step (configs[2] is N = 8: spp 1024).  Per-GPU work is constant: weak scaling.
+
+Launch: python bench.py --gpus 1 ...   or
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+               --master-port P bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W_IMG, H_IMG, SPP_PER_GPU, DEPTH = 1200, 800, 128, 50
+SCENE_SEED, RENDER_SEED = 1, 1
+PEAK_VALU_TFLOPS = 78.6    # fp32 VALU without FMA: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md: 157.3 TF is the FMA figure)
+PEAK_HBM_GBS = 8000.0      # HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured float4 copy
+FLOPS_PER_SPHERE_TEST = 18  # Sphere::Intersect up to the discriminant: 9 mul + 9 add/sub
+BYTES_PER_SPHERE_TEST = 16  # one (cx,cy,cz,r^2) record
+
+
+def cpu_baseline(target_seconds=15.0):
+    """The oracle (CPU restatement; kind 'port') timed on this box's host cores on a bounded sample of
+    the same workload: the full 1200x800 cover frame at a reduced spp (cost is exactly linear in spp),
+    BvhNode traversal as in the reference, std::thread workers."""
+    from oracle import oracle_py as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    # a one-GPU box's CPU share is 16 cores; RT_CPU_BASELINE_THREADS overrides
+    cores = int(os.environ.get("RT_CPU_BASELINE_THREADS", min(avail, 16)))
+    sc = O.build_scene("cover", SCENE_SEED, W_IMG / float(H_IMG))
+    orc = O.Oracle()
+    orc.upload(sc)
+    t0 = time.perf_counter()
+    st = orc.render(W_IMG, H_IMG, 1, 2, DEPTH, RENDER_SEED, accel=O.ACCEL_BVH, threads=cores)
+    orc.resolve()
+    t1 = time.perf_counter() - t0
+    spp = int(max(1, min(SPP_PER_GPU, round(target_seconds / max(t1, 1e-3)))))
+    if spp > 1:
+        t0 = time.perf_counter()
+        st = orc.render(W_IMG, H_IMG, 1, 1 + spp, DEPTH, RENDER_SEED, accel=O.ACCEL_BVH, threads=cores)
+        orc.resolve()
+        t1 = time.perf_counter() - t0
+    return {"value": st.samples / t1 / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "cover scene %dx%d depth %d at spp=%d (of %d), BvhNode traversal, %d std::thread workers, %.1f s"
+                      % (W_IMG, H_IMG, DEPTH, spp, SPP_PER_GPU, cores, t1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    N = args.gpus
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if N > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as g
+    if rank == 0:
+        g.build()
+    if dist is not None:
+        dist.barrier()
+    from cpuraytracer_amd import HipRenderer, scenes, distributed as D
+
+    spp = SPP_PER_GPU * N
+    r = HipRenderer(local_rank)
+    stream = torch.cuda.Stream()  # a real (non-null) HIP stream: kernels, copies, events and the gather are ordered on it
+    torch.cuda.set_stream(stream)
+    r.set_stream(stream.cuda_stream)
+    sc = scenes.build_scene("cover", SCENE_SEED, W_IMG, H_IMG)
+    r.upload(sc)  # scene resident in HBM before the timed region
+    rs = D.shard_rowset(H_IMG, rank, N)
+    rows = D.local_rows(H_IMG, rank, N)
+    hdr_strip = torch.empty((rows, W_IMG, 3), dtype=torch.float32, device="cuda")
+    ldr_strip = torch.empty((rows, W_IMG, 3), dtype=torch.uint8, device="cuda")
+
+    kernel_ms, trav, last = [], [], None
+
+    def step():
+        nonlocal last
+        st = r.render(W_IMG, H_IMG, 1, 1 + spp, DEPTH, RENDER_SEED, rowset=rs)
+        r.resolve()
+        r.copy_to_device(hdr_strip.data_ptr(), ldr_strip.data_ptr())
+        parts_h = D.gather_strip(hdr_strip, H_IMG, rank, N)  # RCCL gather of tile rows (no-op at N = 1)
+        parts_l = D.gather_strip(ldr_strip, H_IMG, rank, N)
+        last = (st, parts_h, parts_l)
+        return st
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = step()
+        kernel_ms.append(st.ms_render)
+        trav.append(st.traversals)
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    # per-rank kernel facts for the roofline object (rank 0's own kernel)
+    n_spheres = sc.n
+    avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+    avg_trav = sum(trav) / max(1, len(trav))
+    tests = avg_trav * n_spheres  # ray-sphere tests per launch of rt_trace_kernel on this rank
+    achieved_tflops = FLOPS_PER_SPHERE_TEST * tests / (avg_ms * 1e-3) / 1e12
+    achieved_gbs = BYTES_PER_SPHERE_TEST * tests / (avg_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        total_samples = W_IMG * H_IMG * spp
+        value = total_samples * args.steps / dt / 1e6
+        st_last, parts_h, parts_l = last
+        # assembling the gathered strips is outside the timed region (host side de-interleave for the PPM)
+        full = D.assemble([p.cpu().numpy() for p in parts_l], H_IMG, N)
+        assert full.shape == (H_IMG, W_IMG, 3)
+        traffic = None
+        tr_path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tr_path):
+            try:
+                traffic = json.load(open(tr_path)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Msamples/sec (WxHxspp/s), 1200x800 cover scene spp=128 d=50",
+            "value": value, "unit": "Msamples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "RTIOW cover scene (%d spheres, scene seed %d) %dx%d spp=%d depth=%d, render seed %d; "
+                                   "rows sharded cyclically over %d GPU(s) in 4-row blocks, RCCL gather of strips to rank 0"
+                                   % (n_spheres, SCENE_SEED, W_IMG, H_IMG, spp, DEPTH, RENDER_SEED, N),
+                       "spp_per_gpu": SPP_PER_GPU, "samples_per_step": total_samples,
+                       "traversals_per_sample": avg_trav / (W_IMG * rows * spp)},
+            "roofline": {"bound": "valu", "kernel": "rt_trace_kernel<LDS tables>", "achieved": achieved_tflops,
+                         "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_VALU_TFLOPS,
+                         "traffic": traffic, "launch_ms": avg_ms,
+                         "algorithmic": "18 flop x %d spheres x %.0f list scans per launch (unfused fp32; peak = 157.3/2)" % (n_spheres, avg_trav)},
+            "hbm_read_equivalent": {"bound": "hbm", "achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": achieved_gbs / PEAK_HBM_GBS,
+                                    "note": "16 B sphere record x tests / kernel time; served from LDS, so it may exceed the HBM roofline"},
+        }
+        if N == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -511,4 +511,69 @@ int rt_unit_trace(rt_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* ijs, uint
     return RT_OK;
 }
 
+int rt_unit_camera_rays(rt_ctx* ctx, const rt_camera* camera, const float* uv_offset, uint32_t n, float* out_rays) {
+    if (!ctx || !camera || !uv_offset || !out_rays) return Fail(RT_ERR_INVALID_ARG, "rt_unit_camera_rays: invalid argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    TmpDev<float> dIn, dOut;
+    RT_HIP(dIn.Alloc((size_t)n * 4));
+    RT_HIP(dOut.Alloc((size_t)n * 6));
+    RT_HIP(hipMemcpy(dIn.p, uv_offset, (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice));
+    rtd::TraceParams tp{};
+    for (int k = 0; k < 3; ++k) {
+        tp.cam_o[k] = camera->origin[k];
+        tp.cam_x[k] = camera->x[k];
+        tp.cam_y[k] = camera->y[k];
+        tp.cam_oip[k] = camera->origin_image_plane[k];
+    }
+    tp.aperture = camera->aperture;
+    tp.focal = camera->focal_length;
+    hipLaunchKernelGGL(rtd::k_unit_camera, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, tp, dIn.p, n, dOut.p);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(hipMemcpy(out_rays, dOut.p, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_unit_scatter(rt_ctx* ctx, const rt_material* material, const rt_light* sun, const float view_origin[3], const float* in,
+                    uint32_t n, float* out) {
+    if (!ctx || !material || !sun || !view_origin || !in || !out) return Fail(RT_ERR_INVALID_ARG, "rt_unit_scatter: invalid argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    TmpDev<float> dIn, dOut;
+    TmpDev<rt_material> dMat;
+    RT_HIP(dIn.Alloc((size_t)n * 12));
+    RT_HIP(dOut.Alloc((size_t)n * 11));
+    RT_HIP(dMat.Alloc(1));
+    RT_HIP(hipMemcpy(dIn.p, in, (size_t)n * 12 * sizeof(float), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(dMat.p, material, sizeof(rt_material), hipMemcpyHostToDevice));
+    rtd::TraceParams tp{};
+    for (int k = 0; k < 3; ++k) {
+        tp.cam_o[k] = view_origin[k];
+        tp.sun_dir[k] = sun->direction[k];
+        tp.sun_rad[k] = sun->luminance * sun->color[k];
+    }
+    hipLaunchKernelGGL(rtd::k_unit_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, tp, dMat.p, dIn.p, n, dOut.p);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(hipMemcpy(out, dOut.p, (size_t)n * 11 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_unit_tonemap(rt_ctx* ctx, const float* hdr_rgb, uint32_t n, uint32_t n_samples, uint8_t* out_rgb) {
+    if (!ctx || !hdr_rgb || !out_rgb || n_samples == 0) return Fail(RT_ERR_INVALID_ARG, "rt_unit_tonemap: invalid argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    TmpDev<float> dIn;
+    TmpDev<uint8_t> dOut;
+    RT_HIP(dIn.Alloc((size_t)n * 3));
+    RT_HIP(dOut.Alloc((size_t)n * 3));
+    RT_HIP(hipMemcpy(dIn.p, hdr_rgb, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rtd::k_unit_tonemap, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dIn.p, n, n_samples, dOut.p);
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(hipMemcpy(out_rgb, dOut.p, (size_t)n * 3, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 }  // extern "C"

@@ -14,12 +14,17 @@
 // times per hit against ~10^4 f32 ops per list scan, so the cost is noise.
 #pragma once
 
-#include <hip/hip_runtime.h>
 #include <stdint.h>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RT_DEV __host__ __device__ __forceinline__
+#else
+// The host mirror (csrc/host/) compiles the same arithmetic with g++ -ffp-contract=off for the
+// once-per-scene work (Camera::Camera, InitScene); nothing on the render path runs on the CPU.
+#define RT_DEV inline
+#endif
 
 namespace rtd {
-
-#define RT_DEV __device__ __forceinline__
 
 struct V3 {
     float x, y, z;
@@ -142,9 +147,9 @@ RT_DEV float rt_powf(float xf, float yf) {
     if (!(xf > 0.f)) return 0.f;
     if (xf == 1.f) return 1.f;
     const double x = (double)xf;
-    const uint64_t bits = (uint64_t)__double_as_longlong(x);
+    const uint64_t bits = __builtin_bit_cast(uint64_t, x);
     int e = (int)((bits >> 52) & 0x7ff) - 1023;
-    double m = __longlong_as_double((long long)((bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL));
+    double m = __builtin_bit_cast(double, (uint64_t)((bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL));
     if (m > 1.41421356237309514547) {
         m = m * 0.5;
         e = e + 1;
@@ -184,7 +189,7 @@ RT_DEV float rt_powf(float xf, float yf) {
     q = q * g + 0.5;
     q = q * g + 1.0;
     q = q * g + 1.0;
-    const double scale = __longlong_as_double((long long)((uint64_t)(1023 + k) << 52));
+    const double scale = __builtin_bit_cast(double, (uint64_t)(1023 + k) << 52);
     return (float)(q * scale);
 }
 

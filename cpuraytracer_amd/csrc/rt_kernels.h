@@ -72,6 +72,22 @@ RT_DEV uint32_t rowset_global_row(const rt_rowset& rs, uint32_t lr) {
     return rs.first_row + (lb * rs.nshards + rs.shard) * rs.block_rows + k;
 }
 
+// Camera::GetRay (camera.cpp:30-48)
+RT_DEV void camera_get_ray(const TraceParams& p, float uvx, float uvy, float lensx, float lensy, V3& origin, V3& dir) {
+    const V3 camO = v3(p.cam_o[0], p.cam_o[1], p.cam_o[2]);
+    const V3 mx = v3(p.cam_x[0], p.cam_x[1], p.cam_x[2]);
+    const V3 my = v3(p.cam_y[0], p.cam_y[1], p.cam_y[2]);
+    const V3 oip = v3(p.cam_oip[0], p.cam_oip[1], p.cam_oip[2]);
+    const float ndcx = 2.f * uvx - 1.f;
+    const float ndcy = -2.f * uvy + 1.f;
+    const V3 pp = (oip + ndcx * mx) + ndcy * my;
+    const V3 focalPoint = camO + p.focal * normalize3(pp - camO);
+    const float rdx = (0.5f * p.aperture) * lensx;
+    const float rdy = (0.5f * p.aperture) * lensy;
+    origin = (camO + rdx * mx) + rdy * my;
+    dir = normalize3(focalPoint - origin);
+}
+
 // ------------------------------------------------------------------ primary rays (A1, A2)
 // SpheresApp::GenerateRays (spheres-app.cpp:132-161) + Camera::GetRay (camera.cpp:30-48) for one
 // (i, j, s).  jitter = Halton2D(s;2,3); lens = HaltonSampleDisk(s+i+j;4,5).
@@ -90,19 +106,7 @@ RT_DEV void gen_primary_ray(const TraceParams& p, uint32_t i, uint32_t j, uint32
     const float lensx = r * (float)cs;
     const float lensy = r * (float)sn;
 
-    const V3 camO = v3(p.cam_o[0], p.cam_o[1], p.cam_o[2]);
-    const V3 mx = v3(p.cam_x[0], p.cam_x[1], p.cam_x[2]);
-    const V3 my = v3(p.cam_y[0], p.cam_y[1], p.cam_y[2]);
-    const V3 oip = v3(p.cam_oip[0], p.cam_oip[1], p.cam_oip[2]);
-
-    const float ndcx = 2.f * uvx - 1.f;
-    const float ndcy = -2.f * uvy + 1.f;
-    const V3 pp = (oip + ndcx * mx) + ndcy * my;
-    const V3 focalPoint = camO + p.focal * normalize3(pp - camO);
-    const float rdx = (0.5f * p.aperture) * lensx;
-    const float rdy = (0.5f * p.aperture) * lensy;
-    origin = (camO + rdx * mx) + rdy * my;
-    dir = normalize3(focalPoint - origin);
+    camera_get_ray(p, uvx, uvy, lensx, lensy, origin, dir);
 }
 
 // ---------------------------------------------------------------------- list scan (A4, A6)
@@ -199,11 +203,27 @@ RT_DEV V3 eval_texture(const Mat& m, float u, float v) {
     return v3(m.rgb0[0], m.rgb0[1], m.rgb0[2]);  // texture.cpp:8-11
 }
 
+// Source of the material draws: the path's xoshiro stream, or (unit tests) scripted uniforms.
+struct StreamDraws {
+    Rng rng;
+    RT_DEV float next() { return rng_uniform(rng); }
+};
+struct ScriptedDraws {
+    float d[3];
+    uint32_t used;
+    RT_DEV float next() {
+        const float v = used < 3 ? d[used] : 0.f;
+        ++used;
+        return v;
+    }
+};
+
 // ------------------------------------------------- hit processing (A8, A10-A13, A15)
 // Runs Material::Scatter (draws first, material.cpp) then DirectionalLight::Shade's unoccluded
 // value (light.cpp:21-40).  Outputs: scattered flag, attenuation, scattered direction, local =
 // Emit + Shade assuming the sun is visible (the caller adds it only if the shadow scan misses).
-RT_DEV bool scatter_and_shade(const TraceParams& p, const Mat& m, V3 rd, V3 pos, V3 nrm, Rng& rng, V3& atten, V3& outDir,
+template <class Draws>
+RT_DEV bool scatter_and_shade(const TraceParams& p, const Mat& m, V3 rd, V3 pos, V3 nrm, Draws& draws, V3& atten, V3& outDir,
                               V3& local) {
     const float uvx = 0.5f * nrm.x + 0.5f;  // Sphere::ComputeUV, ray-tracing.cpp:26-40
     const float uvy = 0.5f * nrm.z + 0.5f;
@@ -228,7 +248,7 @@ RT_DEV bool scatter_and_shade(const TraceParams& p, const Mat& m, V3 rd, V3 pos,
         const V3 refr = refract3(rd, outwardNormal, niOverNt);
         const bool canRefract = (refr.x != 0.f) || (refr.y != 0.f) || (refr.z != 0.f);
         const float prob = canRefract ? fresnel_term(cosI, m.ior) : 1.f;
-        const float u = rng_uniform(rng);
+        const float u = draws.next();
         if (prob > u) outDir = normalize3(reflect3(rd, nrm));
         else outDir = normalize3(refr);
         scattered = true;
@@ -237,7 +257,7 @@ RT_DEV bool scatter_and_shade(const TraceParams& p, const Mat& m, V3 rd, V3 pos,
         if (ndv > 0.f) {
             // The 4-lane coin (XMVectorGreaterR + AnyTrue) is always true: lane w of f0 is the
             // colour's alpha = 1, so R.w = 1 > u.  The draw is still consumed (material.cpp:82).
-            (void)rng_uniform(rng);
+            (void)draws.next();
             atten = tex;
             outDir = normalize3(reflect3(rd, nrm));
             scattered = true;
@@ -247,14 +267,14 @@ RT_DEV bool scatter_and_shade(const TraceParams& p, const Mat& m, V3 rd, V3 pos,
         if (ndv > 0.f) {
             const float nDotV = sat1(ndv);
             const float refl = 0.04f + (1.f - 0.04f) * rt_powf(1.f - nDotV, 5.f);
-            const float u = rng_uniform(rng);
+            const float u = draws.next();
             if (refl > u) {
                 atten = v3(1.f, 1.f, 1.f);
                 outDir = normalize3(reflect3(rd, nrm));
             } else {
                 atten = tex;
-                const float u1 = rng_uniform(rng);  // HaltonSampleHemisphere's two dimensions
-                const float u2 = rng_uniform(rng);
+                const float u1 = draws.next();  // HaltonSampleHemisphere's two dimensions
+                const float u2 = draws.next();
                 const float r = __builtin_sqrtf(1.f - u1 * u1);  // quasi-random.cpp:41
                 const float phi = (2.f * 3.141592654f) * u2;
                 double sn, cs;
@@ -340,7 +360,7 @@ __global__ void __launch_bounds__(256) rt_trace_kernel(const TraceParams p) {
     V3 ro = v3(0.f, 0.f, 0.f), rd = v3(0.f, 0.f, 1.f);  // current ray
     V3 thr = v3(1.f, 1.f, 1.f), rad = v3(0.f, 0.f, 0.f);
     V3 pend = v3(0.f, 0.f, 0.f), nextDir = v3(0.f, 0.f, 0.f);
-    Rng rng{1u, 0u, 0u, 0u};
+    StreamDraws draws{Rng{1u, 0u, 0u, 0u}};
     uint32_t q = 0, depth = 0, state = kIdle, pathTrav = 0;
     bool contAfterShadow = false;
     uint32_t nTrav = 0, nSeg = 0;
@@ -381,7 +401,7 @@ __global__ void __launch_bounds__(256) rt_trace_kernel(const TraceParams p) {
                     i = pl - lr * p.W;
                     j = rowset_global_row(p.rs, lr);
                 }
-                rng = rng_seed(p.seed, j * p.W + i, s);
+                draws.rng = rng_seed(p.seed, j * p.W + i, s);
                 gen_primary_ray(p, i, j, s, ro, rd);
                 thr = v3(1.f, 1.f, 1.f);
                 rad = v3(0.f, 0.f, 0.f);
@@ -420,7 +440,7 @@ __global__ void __launch_bounds__(256) rt_trace_kernel(const TraceParams p) {
                 const V3 pos = tmin * rd + ro;          // XMVectorMultiplyAdd(t, dir, origin), ray-tracing.cpp:57
                 const V3 nrm = (pos - center) / radius;  // ray-tracing.cpp:58
                 V3 atten, local;
-                const bool scattered = scatter_and_shade(p, m, rd, pos, nrm, rng, atten, nextDir, local);
+                const bool scattered = scatter_and_shade(p, m, rd, pos, nrm, draws, atten, nextDir, local);
                 pend = thr * local;
                 contAfterShadow = (depth < p.max_depth) && scattered;  // spheres-app.cpp:247
                 thr = thr * atten;
@@ -539,6 +559,40 @@ __global__ void k_unit_closest(const TraceParams p, const float* rays, uint32_t 
         w[8] = 0.5f * nrm.x + 0.5f;
         w[9] = 0.5f * nrm.z + 0.5f;
     }
+}
+
+// Camera::GetRay for given (uv, lens offset) pairs: in 4 floats, out origin xyz + direction xyz.
+__global__ void k_unit_camera(const TraceParams p, const float* uvoff, uint32_t n, float* out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float uvx = uvoff[4 * k], uvy = uvoff[4 * k + 1], lensx = uvoff[4 * k + 2], lensy = uvoff[4 * k + 3];
+    V3 o, d;
+    camera_get_ray(p, uvx, uvy, lensx, lensy, o, d);
+    float* w = out + 6 * (size_t)k;
+    w[0] = o.x; w[1] = o.y; w[2] = o.z; w[3] = d.x; w[4] = d.y; w[5] = d.z;
+}
+// Material::Scatter + Emit + unoccluded DirectionalLight::Shade for one material record.
+// in: ray dir 3, pos 3, normal 3, draws 3 (12 floats); out: scattered, atten 3, dir 3, draws used, local 3 (11 floats)
+__global__ void k_unit_scatter(const TraceParams p, const rt_material* mat, const float* in, uint32_t n, float* out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float* q = in + 12 * (size_t)k;
+    const Mat m = load_material(mat, 0);
+    ScriptedDraws draws{{q[9], q[10], q[11]}, 0u};
+    V3 atten, dir, local;
+    const bool sc = scatter_and_shade(p, m, v3(q[0], q[1], q[2]), v3(q[3], q[4], q[5]), v3(q[6], q[7], q[8]), draws, atten, dir, local);
+    float* w = out + 11 * (size_t)k;
+    w[0] = sc ? 1.f : 0.f;
+    w[1] = atten.x; w[2] = atten.y; w[3] = atten.z;
+    w[4] = dir.x; w[5] = dir.y; w[6] = dir.z;
+    w[7] = (float)draws.used;
+    w[8] = local.x; w[9] = local.y; w[10] = local.z;
+}
+// Resolve for given HDR triples (tonemap unit test): in 3 floats, out 3 bytes
+__global__ void k_unit_tonemap(const float* hdr, uint32_t n, uint32_t nSamples, uint8_t* out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    for (int ch = 0; ch < 3; ++ch) out[3 * (size_t)k + ch] = (uint8_t)rne_u8(tonemap_channel(hdr[3 * (size_t)k + ch], (float)nSamples));
 }
 
 }  // namespace rtd

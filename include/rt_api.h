@@ -198,6 +198,16 @@ int rt_unit_closest_hit(rt_ctx* ctx, const float* rays, uint32_t n, float* out_h
 int rt_unit_trace(rt_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* ijs, uint32_t n,
                   uint32_t max_depth, uint64_t seed, float* out_rgb, uint32_t* out_traversals);
 
+/* Camera::GetRay (camera.cpp:30-48) for (uv.x, uv.y, offset.x, offset.y) quadruples -> origin xyz, direction xyz */
+int rt_unit_camera_rays(rt_ctx* ctx, const rt_camera* camera, const float* uv_offset, uint32_t n, float* out_rays);
+/* Material::Scatter (material.cpp:20-164) + Emit + unoccluded DirectionalLight::Shade (light.cpp:21-40) for one
+ * material record.  in: ray direction 3, hit pos 3, hit normal 3, three uniforms consumed in call order (12 floats);
+ * out: scattered flag, attenuation 3, scattered direction 3, draws consumed, Emit+Shade 3 (11 floats). */
+int rt_unit_scatter(rt_ctx* ctx, const rt_material* material, const rt_light* sun, const float view_origin[3],
+                    const float* in, uint32_t n, float* out);
+/* The resolve of spheres-app.cpp:196-214 for given HDR triples -> R,G,B bytes */
+int rt_unit_tonemap(rt_ctx* ctx, const float* hdr_rgb, uint32_t n, uint32_t n_samples, uint8_t* out_rgb);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,9 @@ void orc_color_load(uint32_t argb, float out[4]);
  * returns scattered flag; out: attenuation[3], dir[3], n_draws */
 int orc_unit_scatter(const rt_material* m, const float ray_dir[3], const float pos[3], const float normal[3], const float uv[2],
                      const float draws[3], float out_atten[3], float out_dir[3], uint32_t* n_draws);
+/* Material::Emit + Material::Shade with an unoccluded sun (light.cpp:21-40) for one hit */
+void orc_unit_emit_shade(const rt_material* m, const rt_light* sun, const float view_origin[3], const float pos[3],
+                         const float normal[3], const float uv[2], float out_local[3]);
 void orc_xoshiro_seed(uint64_t seed, uint32_t pixel_id, uint32_t sample, uint32_t out_state[4]);
 void orc_xoshiro_draws(uint64_t seed, uint32_t pixel_id, uint32_t sample, uint32_t n, float* out);
 void orc_tonemap(const float hdr_rgb[3], uint32_t n_samples, uint8_t out_rgb[3]);

@@ -243,6 +243,27 @@ int orc_unit_scatter(const rt_material* m, const float ray_dir[3], const float p
     return scattered ? 1 : 0;
 }
 
+void orc_unit_emit_shade(const rt_material* m, const rt_light* sun, const float view_origin[3], const float pos[3],
+                         const float normal[3], const float uv[2], float out_local[3]) {
+    FlatScene fs;
+    fs.spheres.push_back({0.f, 0.f, 0.f, 1.f});
+    fs.materials.push_back(*m);
+    fs.camera = rt_camera{};
+    fs.sun = *sun;
+    fs.sky = rt_material{};
+    SpheresApp app;
+    app.LoadScene(fs, 1);
+    std::vector<std::unique_ptr<Light>> lights;
+    lights.push_back(std::make_unique<DirectionalLight>(*sun, [](const Ray&) { return false; }));
+    Payload hit{};
+    hit.pos = XMVectorSet(pos[0], pos[1], pos[2], 0.f);
+    hit.normal = XMVectorSet(normal[0], normal[1], normal[2], 0.f);
+    hit.uv = XMFLOAT2(uv[0], uv[1]);
+    const Material* mat = app.MaterialOf(0);
+    const XMVECTOR local = mat->Emit(hit) + mat->Shade(hit, lights, XMVectorSet(view_origin[0], view_origin[1], view_origin[2], 1.f));
+    out_local[0] = local.x; out_local[1] = local.y; out_local[2] = local.z;
+}
+
 void orc_xoshiro_seed(uint64_t seed, uint32_t pixel_id, uint32_t sample, uint32_t out_state[4]) {
     Xoshiro128 x;
     x.Seed(seed, pixel_id, sample);

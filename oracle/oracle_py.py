@@ -110,6 +110,8 @@ def lib():
         L.orc_unit_scatter.argtypes = [C.POINTER(RtMaterial), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                        C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                        C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        L.orc_unit_emit_shade.argtypes = [C.POINTER(RtMaterial), C.POINTER(RtLight), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                          C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_xoshiro_seed.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
         L.orc_xoshiro_draws.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_tonemap.argtypes = [C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint8)]
@@ -172,8 +174,15 @@ class Oracle:
             pass
 
     def upload(self, scene):
-        _check(lib().orc_scene_upload(self._h, scene.spheres.ctypes.data, scene.materials.ctypes.data, scene.n,
-                                      C.byref(scene.camera), C.byref(scene.sun), C.byref(scene.sky), scene.exposure_scale))
+        """scene: any object with the rt_api.h tables (the oracle's own Scene or the product's)."""
+        sph = np.ascontiguousarray(scene.spheres)
+        mat = np.ascontiguousarray(scene.materials)
+        assert sph.dtype.itemsize == 16 and mat.dtype.itemsize == 48
+        cam = RtCamera.from_buffer_copy(bytes(scene.camera))
+        sun = RtLight.from_buffer_copy(bytes(scene.sun))
+        sky = RtMaterial.from_buffer_copy(bytes(scene.sky))
+        _check(lib().orc_scene_upload(self._h, sph.ctypes.data, mat.ctypes.data, sph.shape[0], C.byref(cam), C.byref(sun),
+                                      C.byref(sky), float(scene.exposure_scale)))
 
     def render(self, W, H, s0, s1, max_depth, seed, rowset=None, accel=ACCEL_LIST, threads=1):
         rs = rowset if rowset is not None else whole_image(H)

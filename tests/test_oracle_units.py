@@ -1,0 +1,443 @@
+"""CPU tests of the oracle (oracle/): known answers from the reference's own quasi-random.cpp,
+closed-form checks of every restated DirectXMath / reference function, and the committed goldens.
+No GPU.  Reference citations are relative to /root/reference/src."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+
+def f32(x):
+    return float(np.float32(x))
+
+
+# ------------------------------------------------------------------ Halton (quasi-random.cpp:3-61)
+def test_halton_known_answers_bit_exact(oracle):
+    ka = json.load(open(os.path.join(GOLDEN, "halton_known_answers.json")))
+    L = oracle.lib()
+    for idx, vals in ka["halton"].items():
+        for base, hx in zip(ka["bases"], vals):
+            got = L.orc_halton(int(idx), base)
+            assert got == float.fromhex(hx), (idx, base, got.hex(), hx)
+
+
+def test_halton_hemisphere_and_disk_known_answers(oracle):
+    ka = json.load(open(os.path.join(GOLDEN, "halton_known_answers.json")))
+    L = oracle.lib()
+    o3, o2 = (C.c_float * 3)(), (C.c_float * 2)()
+    for idx, want in ka["hemisphere_5_7_tol_1e-6"].items():
+        L.orc_halton_hemisphere(int(idx), 5, 7, o3)
+        assert np.allclose(list(o3), want, atol=1e-6)
+    for idx, want in ka["disk_4_5_tol_1e-6"].items():
+        L.orc_halton_disk(int(idx), 4, 5, o2)
+        assert np.allclose(list(o2), want, atol=1e-6)
+
+
+def test_halton_index_zero_and_range(oracle):
+    idx = np.arange(0, 5000, dtype=np.uint32)
+    for base in (2, 3, 4, 5, 7):
+        h = oracle.halton_array(idx, base)
+        assert h[0] == 0.0 and (h >= 0).all() and (h < 1).all()
+    # base 2 is the bit-reversal: H(i;2) for i = 2^k is 2^-(k+1) exactly
+    for k in range(20):
+        assert oracle.lib().orc_halton(1 << k, 2) == 2.0 ** -(k + 1)
+
+
+def test_hemisphere_is_uniform_in_z_not_cosine_weighted(oracle):
+    # quasi-random.cpp:36-50 — z = u1 (uniform solid angle); unit length
+    L = oracle.lib()
+    o3 = (C.c_float * 3)()
+    zs = []
+    for i in range(1, 400):
+        L.orc_halton_hemisphere(i, 5, 7, o3)
+        v = np.array(list(o3), dtype=np.float64)
+        assert abs(np.linalg.norm(v) - 1.0) < 1e-6 and v[2] >= 0
+        assert f32(v[2]) == L.orc_halton(i, 5)
+        zs.append(v[2])
+    assert abs(np.mean(zs) - 0.5) < 0.02  # cosine weighting would give 2/3
+
+
+def test_disk_radius_is_not_sqrt(oracle):
+    # quasi-random.cpp:52-61 — r = H(i;b2) without sqrt (centre-weighted)
+    L = oracle.lib()
+    o2 = (C.c_float * 2)()
+    for i in range(1, 200):
+        L.orc_halton_disk(i, 4, 5, o2)
+        assert abs(math.hypot(o2[0], o2[1]) - L.orc_halton(i, 5)) < 1e-6
+
+
+# ------------------------------------------------------ elementary-function contract
+def test_sin_cos_pow_are_correctly_rounded_on_samples(oracle):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(0, 2 * np.pi, 200000), [0, np.pi / 2, np.pi, 1.5 * np.pi, 2 * np.pi]]).astype(np.float32)
+    for op, fn in ((0, np.sin), (1, np.cos)):
+        got = oracle.math_array(op, x)
+        assert np.array_equal(got, fn(x.astype(np.float64)).astype(np.float32))
+    xb = rng.uniform(0, 1, 200000).astype(np.float32)
+    for y in (5.0, 16.0, 32.0, 39.99, 1 / 2.2):
+        yy = np.full_like(xb, np.float32(y))
+        got = oracle.math_array(2, xb, yy)
+        assert np.array_equal(got, np.power(xb.astype(np.float64), yy.astype(np.float64)).astype(np.float32))
+
+
+def test_pow_special_cases(oracle):
+    x = np.array([0, 0, 1, 0.5, 1e-30, 0.25], dtype=np.float32)
+    y = np.array([0, 3, 7, 0, 40, 0.5], dtype=np.float32)
+    got = oracle.math_array(2, x, y)
+    assert list(got) == [1.0, 0.0, 1.0, 1.0, 0.0, 0.5]
+
+
+def test_tan_matches_libm_to_1ulp(oracle):
+    x = np.random.default_rng(1).uniform(0.01, 1.5, 10000).astype(np.float32)
+    got = oracle.math_array(3, x)
+    ref = np.tan(x.astype(np.float64))
+    assert np.max(np.abs(got - ref) / np.abs(ref)) < 1.2e-7
+
+
+# ----------------------------------------------------------- DirectXMath restatements
+def test_fresnel_term_closed_forms(oracle):
+    L = oracle.lib()
+    assert abs(L.orc_fresnel_term(1.0, 1.5) - 0.04) < 1e-7  # SURVEY.md §8(c) check value
+    assert L.orc_fresnel_term(0.0, 1.5) == 1.0                # grazing
+    # unpolarised Fresnel reflectance for n = 1.5 at 45 degrees
+    c = math.cos(math.radians(45))
+    g = math.sqrt(1.5 ** 2 - 1 + c * c)
+    want = 0.5 * (g - c) ** 2 / (g + c) ** 2 * (((c * (g + c) - 1) ** 2) / ((c * (g - c) + 1) ** 2) + 1)
+    assert abs(L.orc_fresnel_term(f32(c), 1.5) - want) < 1e-6
+
+
+def test_refract_snell_and_total_internal_reflection(oracle):
+    L = oracle.lib()
+    out = (C.c_float * 3)()
+    th = math.radians(30)
+    I = (C.c_float * 3)(math.sin(th), -math.cos(th), 0.0)
+    N = (C.c_float * 3)(0.0, 1.0, 0.0)
+    L.orc_refract(I, N, 1 / 1.5, out)
+    sin_t = math.hypot(out[0], out[2]) / math.sqrt(sum(v * v for v in out))
+    assert abs(sin_t - math.sin(th) / 1.5) < 1e-6 and out[1] < 0
+    # inside glass beyond the critical angle (41.8 deg): zero vector
+    th = math.radians(60)
+    I = (C.c_float * 3)(math.sin(th), -math.cos(th), 0.0)
+    L.orc_refract(I, N, 1.5, out)
+    assert list(out) == [0.0, 0.0, 0.0]
+
+
+def test_reflect(oracle):
+    L = oracle.lib()
+    out = (C.c_float * 3)()
+    L.orc_reflect((C.c_float * 3)(1, -1, 0), (C.c_float * 3)(0, 1, 0), out)
+    assert list(out) == [1.0, 1.0, 0.0]
+
+
+def test_xmcolor_quantisation(oracle):
+    L = oracle.lib()
+    # XMCOLOR(r,g,b,a): rne(sat(c)*255), ARGB word with B in the low byte
+    c = L.orc_color_pack(0.9, 0.5, 0.1, 1.0)
+    assert ((c >> 16) & 255, (c >> 8) & 255, c & 255, c >> 24) == (230, 128, 26, 255)  # 229.5 -> 230 (even), 127.5 -> 128
+    assert L.orc_color_pack(2.0, -1.0, 0.0, 1.0) == 0xFFFF0000
+    out = (C.c_float * 4)()
+    L.orc_color_load(c, out)
+    k = np.float32(1.0) / np.float32(255.0)
+    assert out[0] == float(np.float32(230) * k) and out[3] == 1.0
+
+
+def test_camera_basis_cover(oracle):
+    # camera.cpp:3-28 for InitCamera (spheres-app.cpp:35-49): left-handed look-at
+    L = oracle.lib()
+    cam = oracle.RtCamera()
+    o = np.array([12, 2, -2.5])
+    la = np.array([0, 1, 0])
+    focal = f32(np.linalg.norm(o - la))
+    L.orc_camera_make((C.c_float * 3)(*o), (C.c_float * 3)(*la), 25.0, 1.5, focal, 0.4, C.byref(cam))
+    w = (la - o) / np.linalg.norm(la - o)
+    u = np.cross([0, 1, 0], w)
+    u /= np.linalg.norm(u)
+    v = np.cross(w, u)
+    hh = math.tan(math.radians(25) / 2)
+    assert np.allclose(list(cam.origin_image_plane)[:3], o + w, atol=1e-5)
+    assert np.allclose(list(cam.x)[:3], 1.5 * hh * u, atol=1e-6)
+    assert np.allclose(list(cam.y)[:3], hh * v, atol=1e-6)
+    assert cam.aperture == f32(0.4) and cam.focal_length == focal
+
+
+def test_tonemap_endpoints(oracle):
+    L = oracle.lib()
+    out = (C.c_uint8 * 3)()
+    L.orc_tonemap((C.c_float * 3)(0, 0, 0), 1, out)
+    # ACES fit at 0: (0*0.03)/(0*0.59+0.14) = 0
+    assert list(out) == [0, 0, 0]
+    L.orc_tonemap((C.c_float * 3)(1e6, 1e6, 1e6), 1, out)
+    assert list(out) == [255, 255, 255]
+    # n divides first: hdr 2.0 over 4 samples == hdr 0.5 over 1
+    a, b = (C.c_uint8 * 3)(), (C.c_uint8 * 3)()
+    L.orc_tonemap((C.c_float * 3)(2.0, 1.0, 0.25), 4, a)
+    L.orc_tonemap((C.c_float * 3)(0.5, 0.25, 0.0625), 1, b)
+    assert list(a) == list(b)
+    c = 0.5
+    want = min(max((c * (2.51 * c + 0.03)) / (c * (2.43 * c + 0.59) + 0.14), 0), 1) ** (1 / 2.2)
+    assert abs(b[0] - want * 255) <= 0.51
+
+
+# ------------------------------------------------------------------- RNG contract (A9)
+def _xoshiro_py(seed, pixel, sample, n):
+    M = (1 << 64) - 1
+
+    def mix(x):
+        x = (x + 0x9E3779B97F4A7C15) & M
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+
+    a = mix(mix(seed) ^ ((pixel << 32) | sample))
+    b = mix(a)
+    s = [a & 0xffffffff, a >> 32, b & 0xffffffff, b >> 32]
+    rotl = lambda x, k: ((x << k) | (x >> (32 - k))) & 0xffffffff
+    out = []
+    for _ in range(n):
+        r = (rotl((s[1] * 5) & 0xffffffff, 7) * 9) & 0xffffffff
+        t = (s[1] << 9) & 0xffffffff
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]
+        s[2] ^= t
+        s[3] = rotl(s[3], 11)
+        out.append((r >> 8) * 2.0 ** -24)
+    return out
+
+
+def test_xoshiro_stream_matches_pure_python(oracle):
+    L = oracle.lib()
+    for seed, pix, s in ((1, 0, 1), (1, 959999, 128), (0xDEADBEEF, 12345, 7), (2 ** 63, 2 ** 24, 1024)):
+        got = np.zeros(16, dtype=np.float32)
+        L.orc_xoshiro_draws(seed, pix, s, 16, got.ctypes.data)
+        assert list(got) == _xoshiro_py(seed, pix, s, 16)
+        assert (got >= 0).all() and (got < 1).all()
+
+
+# --------------------------------------------------------------- scatter (material.cpp)
+_K255 = np.float32(1.0) / np.float32(255.0)
+ALBEDO = [float(np.float32(b) * _K255) for b in (128, 64, 32)]  # table colours are XMLoadColor values: byte * (1/255)
+
+
+def _scatter(oracle, mtype, ray_dir, normal, draws, rgb=ALBEDO, smooth=16.0, ior=1.5):
+    m = oracle.RtMaterial()
+    m.type, m.tex_type, m.smoothness, m.ior = mtype, 0, smooth, ior
+    m.rgb0[0], m.rgb0[1], m.rgb0[2] = rgb
+    att, d, nd = (C.c_float * 3)(), (C.c_float * 3)(), C.c_uint32()
+    f3 = lambda v: (C.c_float * 3)(*v)
+    sc = oracle.lib().orc_unit_scatter(C.byref(m), f3(ray_dir), f3((0, 0, 0)), f3(normal), (C.c_float * 2)(0.5, 0.5), f3(draws), att, d,
+                                       C.byref(nd))
+    return sc, list(att), list(d), nd.value
+
+
+def test_opaque_scatter_draw_counts_and_branches(oracle):
+    n = (0.0, 1.0, 0.0)
+    down = (0.0, -1.0, 0.0)
+    # head-on: Schlick R = 0.04; coin u=0.5 -> diffuse: 3 draws, attenuation = albedo
+    sc, att, d, nd = _scatter(oracle, 0, down, n, (0.5, 0.3, 0.7))
+    assert sc == 1 and nd == 3 and att == ALBEDO and d[1] > 0 and abs(np.linalg.norm(d) - 1) < 1e-6
+    # coin u=0.01 < 0.04 -> mirror: 1 draw, attenuation 1, direction = reflect
+    sc, att, d, nd = _scatter(oracle, 0, down, n, (0.01, 0.3, 0.7))
+    assert sc == 1 and nd == 1 and att == [1.0, 1.0, 1.0] and d == [0.0, 1.0, 0.0]
+    # back-facing: no scatter, no draw (material.cpp:22,61-64)
+    sc, att, d, nd = _scatter(oracle, 0, (0.0, 1.0, 0.0), n, (0.5, 0.3, 0.7))
+    assert sc == 0 and nd == 0
+
+
+def test_metal_always_reflects_but_consumes_one_draw(oracle):
+    # material.cpp:81-85: XMVectorGreaterR over four lanes, lane w = alpha = 1 -> always true
+    n = (0.0, 1.0, 0.0)
+    for u in (0.0, 0.5, 0.999999):
+        sc, att, d, nd = _scatter(oracle, 1, (0.6, -0.8, 0.0), n, (u, 0, 0))
+        assert sc == 1 and nd == 1 and att == ALBEDO
+        assert np.allclose(d, [0.6, 0.8, 0.0], atol=1e-6)
+    sc, _, _, nd = _scatter(oracle, 1, (0.0, 1.0, 0.0), n, (0.5, 0, 0))
+    assert sc == 0 and nd == 0
+
+
+def test_glass_scatter_reflect_vs_refract(oracle):
+    n = (0.0, 1.0, 0.0)
+    # entering head-on: Fresnel(1, 1.5) = 0.04; u = 0.5 -> refract straight through
+    sc, att, d, nd = _scatter(oracle, 2, (0.0, -1.0, 0.0), n, (0.5, 0, 0))
+    assert sc == 1 and nd == 1 and att == [1.0, 1.0, 1.0] and np.allclose(d, [0, -1, 0], atol=1e-6)
+    sc, att, d, nd = _scatter(oracle, 2, (0.0, -1.0, 0.0), n, (0.01, 0, 0))
+    assert np.allclose(d, [0, 1, 0], atol=1e-6)
+    # leaving at 60 degrees: total internal reflection, probability 1 -> reflect for any u
+    th = math.radians(60)
+    sc, att, d, nd = _scatter(oracle, 2, (math.sin(th), math.cos(th), 0.0), n, (0.999, 0, 0))
+    assert sc == 1 and nd == 1 and d[1] < 0
+
+
+# ------------------------------------------------------------ scene generation (A18)
+def test_cover_scene_matches_committed_dump(oracle):
+    g = np.load(os.path.join(GOLDEN, "cover_seed1_scene.npz"))
+    sc = oracle.build_scene("cover", 1, 1.5)
+    assert sc.n == 488  # 1 floor + 22*22 small + 3 large (spheres-app.cpp:60-114)
+    assert np.array_equal(sc.spheres, g["spheres"]) and sc.materials.tobytes() == g["materials"].tobytes()
+    assert bytes(sc.camera) == g["camera"].tobytes() and bytes(sc.sun) == g["sun"].tobytes()
+    assert sc.exposure_scale == 2.0 ** -15
+    t = sc.materials["type"]
+    assert t[0] == 0 and sc.materials["tex_type"][0] == 1 and sc.materials["tiling"][0] == 2500.0
+    assert list(t[-3:]) == [2, 0, 1]  # glass, opaque, metal big spheres
+    small = sc.spheres[1:485]
+    assert (small["r"] == np.float32(0.2)).all() and (small["cy"] == np.float32(0.2)).all()
+
+
+def test_scene_seed_changes_scene_and_grid10k_size(oracle):
+    a = oracle.build_scene("cover", 1, 1.5)
+    b = oracle.build_scene("cover", 2, 1.5)
+    assert not np.array_equal(a.spheres, b.spheres)
+    g = oracle.build_scene("grid10k", 1, 1.0)
+    assert g.n == 10004
+
+
+def test_product_host_scene_equals_oracle_scene(oracle):
+    from cpuraytracer_amd import scenes
+    for name, w, h, ap in (("cover", 1200, 800, -1.0), ("three", 200, 100, -1.0), ("grid10k", 512, 512, -1.0), ("cover", 1920, 1080, 2.0)):
+        a = scenes.build_scene(name, 1, w, h, aperture=ap)
+        b = oracle.build_scene(name, 1, float(np.float32(w) / np.float32(h)), ap)
+        assert np.array_equal(a.spheres, b.spheres) and a.materials.tobytes() == b.materials.tobytes()
+        assert bytes(a.camera) == bytes(b.camera) and bytes(a.sun) == bytes(b.sun) and bytes(a.sky) == bytes(b.sky)
+        assert a.exposure_scale == b.exposure_scale
+
+
+# ----------------------------------------------------------------- intersection (A4-A6)
+def test_sphere_intersect_roots_and_bias(oracle):
+    sc = oracle.build_scene("three", 1, 2.0)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    # ray from the origin along +z hits sphere 0 (centre (0,0,1), r 0.5) at t = 0.5
+    h = orc.closest_hit(np.array([[0, 0, 0, 0, 0, 1]], dtype=np.float32))[0]
+    assert h[0] == 0.5 and h[1:2].view(np.int32)[0] == 0 and np.allclose(h[2:5], [0, 0, 0.5]) and np.allclose(h[5:8], [0, 0, -1])
+    assert np.allclose(h[8:10], [0.5, 0.0])  # planar uv: (0.5*nx+0.5, 0.5*nz+0.5)
+    # from inside the sphere: near root negative -> far root
+    h = orc.closest_hit(np.array([[0, 0, 1, 0, 0, 1]], dtype=np.float32))[0]
+    assert h[0] == 0.5 and np.allclose(h[5:8], [0, 0, 1])
+    # starting ON the surface going out: both roots <= bias 0.001 for this sphere -> next hit or miss
+    h = orc.closest_hit(np.array([[0, 0, 1.5, 0, 0, 1]], dtype=np.float32))[0]
+    assert h[1:2].view(np.int32)[0] == -1
+    # miss upward
+    h = orc.closest_hit(np.array([[0, 5, 0, 0, 1, 0]], dtype=np.float32))[0]
+    assert h[1:2].view(np.int32)[0] == -1
+
+
+def test_bvh_equals_list_on_random_rays_and_images(oracle):
+    sc = oracle.build_scene("cover", 1, 1.5)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    rng = np.random.default_rng(3)
+    n = 5000
+    o = np.stack([rng.uniform(-12, 12, n), rng.uniform(0.05, 4, n), rng.uniform(-12, 12, n)], 1)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d], 1).astype(np.float32)
+    a = orc.closest_hit(rays, oracle.ACCEL_LIST)
+    b = orc.closest_hit(rays, oracle.ACCEL_BVH)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    s1 = orc.render(120, 80, 1, 3, 50, 1, accel=oracle.ACCEL_LIST, threads=4)
+    h1, _ = orc.download()
+    s2 = orc.render(120, 80, 1, 3, 50, 1, accel=oracle.ACCEL_BVH, threads=4)
+    h2, _ = orc.download()
+    assert np.array_equal(h1.view(np.uint32), h2.view(np.uint32)) and s1.traversals == s2.traversals
+
+
+# ------------------------------------------------------------------------ render loop
+def test_c1_matches_committed_golden(oracle):
+    g = np.load(os.path.join(GOLDEN, "c1_three_200x100_spp1_d8.npz"))
+    sc = oracle.build_scene("three", 1, 2.0)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    st = orc.render(200, 100, 1, 2, 8, 1)
+    orc.resolve()
+    hdr, ldr = orc.download()
+    assert np.array_equal(hdr.view(np.uint32), g["hdr"].view(np.uint32)) and np.array_equal(ldr, g["ldr"])
+    assert st.traversals == int(g["traversals"]) and st.segments == int(g["segments"]) and st.samples == 20000
+    # sky rows are exactly the sky emitter times exposure: 8000 * colour * 2^-15
+    sky = np.array([217, 232, 250], dtype=np.float32) * (np.float32(1) / np.float32(255)) * np.float32(8000) * np.float32(2.0 ** -15)
+    assert np.array_equal(hdr[0, 0], sky)
+
+
+def test_cover_small_matches_committed_golden_and_threads_do_not_matter(oracle):
+    g = np.load(os.path.join(GOLDEN, "cover_96x64_spp4_d50.npz"))
+    sc = oracle.build_scene("cover", 1, 1.5)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    for threads in (1, 5):
+        st = orc.render(96, 64, 1, 5, 50, 1, threads=threads)
+        orc.resolve()
+        hdr, ldr = orc.download()
+        assert np.array_equal(hdr.view(np.uint32), g["hdr"].view(np.uint32)) and np.array_equal(ldr, g["ldr"])
+        assert st.traversals == int(g["traversals"])
+
+
+def test_per_sample_golden_vectors(oracle):
+    g = np.load(os.path.join(GOLDEN, "c2_cover_1200x800_samples.npz"))
+    sc = oracle.build_scene("cover", 1, 1.5)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    rgb, trav = orc.trace(1200, 800, g["ijs"], 50, 1)
+    assert np.array_equal(rgb.view(np.uint32), g["rgb"].view(np.uint32)) and np.array_equal(trav, g["traversals"])
+    assert trav.max() <= 2 * 51  # at most depth 0..50 segments, two scans each
+    rays = orc.primary_rays(1200, 800, g["ijs"])
+    assert np.array_equal(rays.view(np.uint32), g["rays"].view(np.uint32))
+    assert np.allclose(np.linalg.norm(rays[:, 3:], axis=1), 1.0, atol=1e-6)
+
+
+def test_progressive_accumulation_and_summation_order(oracle):
+    sc = oracle.build_scene("three", 1, 2.0)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    orc.render(64, 32, 1, 9, 8, 7)
+    one, _ = orc.download()
+    orc.render(64, 32, 1, 4, 8, 7)
+    orc.render(64, 32, 4, 9, 8, 7)
+    two, _ = orc.download()
+    assert np.array_equal(one.view(np.uint32), two.view(np.uint32))
+    # hdr[pixel] is the sequential float sum of the per-sample values in increasing s (spheres-app.cpp:182-183)
+    ijs = np.array([[10, 20, s] for s in range(1, 9)], dtype=np.uint32)
+    rgb, _ = orc.trace(64, 32, ijs, 8, 7)
+    acc = np.zeros(3, dtype=np.float32)
+    for k in range(8):
+        acc = acc + rgb[k]
+    assert np.array_equal(acc, one[20, 10])
+    with pytest.raises(RuntimeError):
+        orc.render(64, 32, 5, 6, 8, 7)  # does not continue at s = 9
+
+
+def test_row_sharding_reassembles_bit_exact(oracle):
+    sc = oracle.build_scene("three", 1, 2.0)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    H, W = 50, 64  # 50 rows: 13 blocks of 4, ragged last block
+    orc.render(W, H, 1, 3, 8, 1)
+    full, _ = orc.download()
+    L = oracle.lib()
+    for world in (2, 3, 8):
+        out = np.zeros_like(full)
+        seen = np.zeros(H, dtype=int)
+        for rank in range(world):
+            rs = oracle.RtRowset(0, H, 4, rank, world)
+            st = orc.render(W, H, 1, 3, 8, 1, rowset=rs)
+            part, _ = orc.download()
+            assert part.shape[0] == L.orc_rowset_local_rows(rs) == st.local_rows
+            for lr in range(part.shape[0]):
+                j = L.orc_rowset_global_row(rs, lr)
+                out[j] = part[lr]
+                seen[j] += 1
+        assert (seen == 1).all() and np.array_equal(out.view(np.uint32), full.view(np.uint32))
+
+
+def test_depth_limit_and_seed_sensitivity(oracle):
+    sc = oracle.build_scene("cover", 1, 1.5)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    ijs = np.array([[600, 500, 1], [610, 520, 2], [300, 700, 3]], dtype=np.uint32)
+    _, t0 = orc.trace(1200, 800, ijs, 0, 1)
+    assert (t0 <= 2).all()  # depth 0: one closest scan (+ one shadow scan on a hit)
+    a, _ = orc.trace(1200, 800, ijs, 50, 1)
+    b, _ = orc.trace(1200, 800, ijs, 50, 2)
+    assert not np.array_equal(a, b)
