@@ -85,10 +85,12 @@ struct rt_ctx {
     DevBuf<float> samples;     // workspace [pixels*spp_pass*3]
     DevBuf<uint32_t> queue;    // [1]
     DevBuf<unsigned long long> counters;  // [2]
+    DevBuf<float2> jitterTab, lensTab;    // ray-generation tables of the current pass
     double lastResolveMs = 0.0;
 
     // tuning (env: RT_BLOCKS_PER_CU, RT_FORCE_GLOBAL_TABLES)
     uint32_t blocksPerCu = 4;
+    uint32_t blockThreads = 256;
     bool forceGlobal = false;
 };
 
@@ -115,14 +117,22 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     const uint32_t maxBlocks = (uint32_t)ctx->cuCount * ctx->blocksPerCu;
     // one wave holds 64 paths; do not launch more waves than there is work for
     const uint64_t wavesNeeded = ((uint64_t)tp.total_paths + 63) / 64;
-    uint32_t blocks = (uint32_t)((wavesNeeded + 3) / 4);
+    const uint32_t wavesPerBlock = ctx->blockThreads / 64;
+    uint32_t blocks = (uint32_t)((wavesNeeded + wavesPerBlock - 1) / wavesPerBlock);
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks == 0) blocks = 1;
+    const size_t ldsBytes = useLds ? lds : 0;
+#define RT_LAUNCH(LDS, T) hipLaunchKernelGGL((rtd::rt_trace_kernel<LDS, T>), dim3(blocks), dim3(T), ldsBytes, ctx->stream, tp)
     if (useLds) {
-        hipLaunchKernelGGL(rtd::rt_trace_kernel<true>, dim3(blocks), dim3(256), lds, ctx->stream, tp);
+        if (ctx->blockThreads == 1024) RT_LAUNCH(true, 1024);
+        else if (ctx->blockThreads == 512) RT_LAUNCH(true, 512);
+        else RT_LAUNCH(true, 256);
     } else {
-        hipLaunchKernelGGL(rtd::rt_trace_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, tp);
+        if (ctx->blockThreads == 1024) RT_LAUNCH(false, 1024);
+        else if (ctx->blockThreads == 512) RT_LAUNCH(false, 512);
+        else RT_LAUNCH(false, 256);
     }
+#undef RT_LAUNCH
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
@@ -165,6 +175,8 @@ int rt_create(int device_ordinal, rt_ctx** out) {
     ctx->blocksPerCu = EnvU32("RT_BLOCKS_PER_CU", 4);
     if (ctx->blocksPerCu == 0) ctx->blocksPerCu = 1;
     ctx->forceGlobal = EnvU32("RT_FORCE_GLOBAL_TABLES", 0) != 0;
+    ctx->blockThreads = EnvU32("RT_BLOCK_THREADS", 256);
+    if (ctx->blockThreads != 256 && ctx->blockThreads != 512 && ctx->blockThreads != 1024) ctx->blockThreads = 256;
     int rc = ctx->queue.Reserve(1);
     if (rc == RT_OK) rc = ctx->counters.Reserve(2);
     if (rc != RT_OK) {
@@ -188,6 +200,8 @@ void rt_destroy(rt_ctx* ctx) {
     ctx->samples.Release();
     ctx->queue.Release();
     ctx->counters.Release();
+    ctx->jitterTab.Release();
+    ctx->lensTab.Release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
@@ -325,7 +339,21 @@ int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, ui
         tp.trav_out = nullptr;
         tp.queue_head = ctx->queue.ptr;
         tp.counters = ctx->counters.ptr;
+        // ray-generation tables for this pass: s in [s, s+spp), k = s+i+j over the strip's rows
+        const uint32_t k0 = s + rs.first_row;
+        const uint32_t nLens = spp + W + rs.num_rows;
+        if ((rc = ctx->jitterTab.Reserve(spp)) != RT_OK) return rc;
+        if ((rc = ctx->lensTab.Reserve(nLens)) != RT_OK) return rc;
+        tp.jitter_tab = ctx->jitterTab.ptr;
+        tp.lens_tab = ctx->lensTab.ptr;
+        tp.lens_k0 = k0;
         RT_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+        {
+            const uint32_t nmax = spp > nLens ? spp : nLens;
+            hipLaunchKernelGGL(rtd::rt_raygen_tables_kernel, dim3((nmax + 255) / 256), dim3(256), 0, ctx->stream, ctx->jitterTab.ptr, s, spp,
+                               ctx->lensTab.ptr, k0, nLens);
+            RT_HIP(hipGetLastError());
+        }
         if ((rc = LaunchTrace(ctx, tp)) != RT_OK) return rc;
         RT_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
         hipLaunchKernelGGL(rtd::rt_accumulate_kernel, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, ctx->samples.ptr, ctx->hdr.ptr,
@@ -499,6 +527,8 @@ int rt_unit_trace(rt_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* ijs, uint
     tp.max_depth = max_depth;
     tp.seed = seed;
     tp.path_list = dIjs.p;
+    tp.jitter_tab = nullptr;
+    tp.lens_tab = nullptr;
     tp.samples = dOut.p;
     tp.trav_out = dTrav.p;
     tp.queue_head = ctx->queue.ptr;

@@ -59,6 +59,9 @@ struct TraceParams {
     uint32_t max_depth;
     uint64_t seed;
     const uint32_t* path_list;  // optional explicit (i, j, s) triples (unit tests)
+    const float2* jitter_tab;   // [spp_pass] Halton2D(s;2,3) for s = s0.. (rt_raygen_tables_kernel), or null
+    const float2* lens_tab;     // [.] HaltonSampleDisk(k;4,5) for k = lens_k0.., or null
+    uint32_t lens_k0;
     float* samples;             // [total_paths][3] radiance * exposure
     uint32_t* trav_out;         // optional per-path traversal counts
     uint32_t* queue_head;       // global work counter, zeroed before launch
@@ -91,20 +94,32 @@ RT_DEV void camera_get_ray(const TraceParams& p, float uvx, float uvy, float len
 // ------------------------------------------------------------------ primary rays (A1, A2)
 // SpheresApp::GenerateRays (spheres-app.cpp:132-161) + Camera::GetRay (camera.cpp:30-48) for one
 // (i, j, s).  jitter = Halton2D(s;2,3); lens = HaltonSampleDisk(s+i+j;4,5).
+RT_DEV void halton_disk_4_5(uint32_t k, float& lensx, float& lensy) {  // quasi-random.cpp:52-61
+    const float theta = (2.f * 3.141592654f) * halton(k, 4);
+    const float r = halton(k, 5);
+    double sn, cs;
+    sincos_f64(theta, sn, cs);
+    lensx = r * (float)cs;
+    lensy = r * (float)sn;
+}
 RT_DEV void gen_primary_ray(const TraceParams& p, uint32_t i, uint32_t j, uint32_t s, V3& origin, V3& dir) {
     const float xsize = (float)p.W;
     const float ysize = (float)p.H;
-    const float jx = halton(s, 2);
-    const float jy = halton(s, 3);
+    float jx, jy, lensx, lensy;
+    const uint32_t li = s + i + j;
+    if (p.jitter_tab) {
+        // the radical inverses depend on s (jitter) and s+i+j (lens) only: a per-pass device kernel
+        // tabulates them so that a refilled lane does two 8-byte loads instead of four divide loops
+        const float2 jt = p.jitter_tab[s - p.s0];
+        const float2 lt = p.lens_tab[li - p.lens_k0];
+        jx = jt.x; jy = jt.y; lensx = lt.x; lensy = lt.y;
+    } else {
+        jx = halton(s, 2);
+        jy = halton(s, 3);
+        halton_disk_4_5(li, lensx, lensy);
+    }
     const float uvx = ((float)(int)i + jx) / xsize;
     const float uvy = ((float)(int)j + jy) / ysize;
-    const uint32_t li = s + i + j;
-    const float theta = (2.f * 3.141592654f) * halton(li, 4);  // quasi-random.cpp:54
-    const float r = halton(li, 5);
-    double sn, cs;
-    sincos_f64(theta, sn, cs);
-    const float lensx = r * (float)cs;
-    const float lensy = r * (float)sn;
 
     camera_get_ray(p, uvx, uvy, lensx, lensy, origin, dir);
 }
@@ -332,8 +347,8 @@ enum : uint32_t { kIdle = 0u, kNeedClosest = 1u, kNeedShadow = 2u };
 // never synchronise with each other after the LDS staging barrier, and every wave's loop ends when
 // the (bounded, monotonically consumed) queue is exhausted and its at most 64 paths of at most
 // max_depth+1 segments have finished.
-template <bool kLds>
-__global__ void __launch_bounds__(256) rt_trace_kernel(const TraceParams p) {
+template <bool kLds, int kThreads>
+__global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p) {
     extern __shared__ float4 smem[];
     const float4* scanTab = p.scan;
     const float* radTab = p.radius;
@@ -459,10 +474,8 @@ __global__ void __launch_bounds__(256) rt_trace_kernel(const TraceParams p) {
             }
         }
         if (finished) {
-            float* out = p.samples + (size_t)q * 3;
-            out[0] = rad.x * p.exposure;  // GetHitColor * exposureAdjustment, spheres-app.cpp:183
-            out[1] = rad.y * p.exposure;
-            out[2] = rad.z * p.exposure;
+            // GetHitColor * exposureAdjustment, spheres-app.cpp:183; one 12-byte store
+            *reinterpret_cast<float3*>(p.samples + (size_t)q * 3) = make_float3(rad.x * p.exposure, rad.y * p.exposure, rad.z * p.exposure);
             if (p.trav_out) p.trav_out[q] = pathTrav;
             state = kIdle;
         }
@@ -480,6 +493,19 @@ __global__ void __launch_bounds__(256) rt_trace_kernel(const TraceParams p) {
     }
 }
 
+// ============================================================ ray-generation tables (A1, A9)
+// jitter[k] = Halton2D(s0+k; 2,3) (spheres-app.cpp:140), lens[k] = HaltonSampleDisk(k0+k; 4,5) (:152)
+__global__ void __launch_bounds__(256) rt_raygen_tables_kernel(float2* jitter, uint32_t s0, uint32_t nJitter, float2* lens, uint32_t k0,
+                                                               uint32_t nLens) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nJitter) jitter[k] = make_float2(halton(s0 + k, 2), halton(s0 + k, 3));
+    if (k < nLens) {
+        float lx, ly;
+        halton_disk_4_5(k0 + k, lx, ly);
+        lens[k] = make_float2(lx, ly);
+    }
+}
+
 // ============================================================== ordered accumulation (A16)
 // hdr[pixel] += sample(pixel, s) for s = s0 .. s0+spp-1 in that order (spheres-app.cpp:182-183).
 __global__ void __launch_bounds__(256) rt_accumulate_kernel(const float* __restrict__ samples, float* __restrict__ hdr, uint32_t npix,
@@ -488,7 +514,20 @@ __global__ void __launch_bounds__(256) rt_accumulate_kernel(const float* __restr
     if (pix >= npix) return;
     float r = hdr[3 * (size_t)pix], g = hdr[3 * (size_t)pix + 1], b = hdr[3 * (size_t)pix + 2];
     const float* sp = samples + (size_t)pix * spp * 3;
-    for (uint32_t s = 0; s < spp; ++s) {
+    uint32_t s = 0;
+    if ((spp & 3u) == 0u) {
+        // 4 samples = 48 B = three aligned 16-byte loads; the adds stay sequential in s
+        const float4* v = reinterpret_cast<const float4*>(sp);
+        for (; s < spp; s += 4) {
+            const float4 a = v[0], c = v[1], d = v[2];
+            v += 3;
+            r += a.x; g += a.y; b += a.z;
+            r += a.w; g += c.x; b += c.y;
+            r += c.z; g += c.w; b += d.x;
+            r += d.y; g += d.z; b += d.w;
+        }
+    }
+    for (; s < spp; ++s) {
         r += sp[3 * s];
         g += sp[3 * s + 1];
         b += sp[3 * s + 2];

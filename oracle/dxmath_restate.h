@@ -300,6 +300,11 @@ inline float rt_powf(float xf, float yf) {
     if (!(xf > 0.f)) return 0.f;  // zero (and, off-domain, negative/NaN) base
     if (xf == 1.f) return 1.f;
     const double x = (double)xf;
+    if (yf == 5.f) {  // Schlick's (1 - n.v)^5 (material.cpp:27,79; light.cpp:37): three exact-order f64 products
+        const double x2 = x * x;
+        const double x4 = x2 * x2;
+        return (float)(x4 * x);
+    }
     const uint64_t bits = f64_bits(x);
     int e = (int)((bits >> 52) & 0x7ff) - 1023;
     double m = f64_from_bits((bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);  // [1,2)
