@@ -113,7 +113,8 @@ static size_t LdsBytesFor(uint32_t n) { return (size_t)PaddedCount(n) * 16 + (si
 static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     RT_HIP(hipMemsetAsync(ctx->queue.ptr, 0, sizeof(uint32_t), ctx->stream));
     const size_t lds = LdsBytesFor(tp.n);
-    const bool useLds = !ctx->forceGlobal && lds <= 64 * 1024;
+    const bool useLds = !ctx->forceGlobal && lds <= 48 * 1024 && tp.n_padded < 65536;
+    if (tp.n_padded >= 65536) return Fail(RT_ERR_INVALID_ARG, "scenes beyond 65,000 spheres are not supported by the 16-bit candidate lists");
     const uint32_t maxBlocks = (uint32_t)ctx->cuCount * ctx->blocksPerCu;
     // one wave holds 64 paths; do not launch more waves than there is work for
     const uint64_t wavesNeeded = ((uint64_t)tp.total_paths + 63) / 64;
@@ -121,8 +122,16 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     uint32_t blocks = (uint32_t)((wavesNeeded + wavesPerBlock - 1) / wavesPerBlock);
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks == 0) blocks = 1;
-    const size_t ldsBytes = useLds ? lds : 0;
-#define RT_LAUNCH(LDS, T) hipLaunchKernelGGL((rtd::rt_trace_kernel<LDS, T>), dim3(blocks), dim3(T), ldsBytes, ctx->stream, tp)
+    // dynamic LDS: per-wave candidate lists (16 slots x 64 lanes x 2 B) + the scene tables when they fit
+    const size_t candBytes = (size_t)wavesPerBlock * 16 * 64 * 2;
+    const size_t ldsBytes = candBytes + (useLds ? lds : 0);
+#define RT_LAUNCH(LDS, T)                                                                                                      \
+    do {                                                                                                                      \
+        if (ldsBytes > 48 * 1024)                                                                                             \
+            RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rtd::rt_trace_kernel<LDS, T>),                           \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));                           \
+        hipLaunchKernelGGL((rtd::rt_trace_kernel<LDS, T>), dim3(blocks), dim3(T), ldsBytes, ctx->stream, tp);                 \
+    } while (0)
     if (useLds) {
         if (ctx->blockThreads == 1024) RT_LAUNCH(true, 1024);
         else if (ctx->blockThreads == 512) RT_LAUNCH(true, 512);

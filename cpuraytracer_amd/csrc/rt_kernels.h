@@ -190,6 +190,108 @@ RT_DEV void scan_list(const float4* __restrict__ tab, uint32_t nPadded, V3 o, V3
     }
 }
 
+// ------------------------------------------------------- list scan with deferred roots
+// The megakernel's scan.  Evaluating roots inside the scan loop serialises the wave over every
+// sphere that ANY of its 64 (incoherent) rays might hit — ~45 mostly-idle VALU instructions per such
+// sphere, about as expensive as a whole group of the branch-free arithmetic.  Instead each lane only
+// RECORDS the groups whose sign test it passes (one predicated 2-byte LDS store) and, after the scan
+// (or when a list is nearly full), every lane walks its OWN list: reload the group's four spheres,
+// recompute the same b and disc (same operations on the same inputs => same bits), and evaluate
+// roots — all lanes busy on different spheres at once.  Lists are processed in increasing sphere
+// index, and the update is a strict `t < tmin`, so the result equals the sequential scan's
+// (lower index wins ties).  A root is impossible — exactly, in IEEE arithmetic — when disc <= 0, or
+// when b > 0 and disc < fl(b*b): then fl(sqrt(disc)) <= fl(sqrt(fl(b*b))) = b, so both numerators
+// -b -/+ sqrt(disc) are <= 0 and neither root exceeds the 0.001 bias (ray-tracing.cpp:52-71).
+constexpr uint32_t kCandSlots = 16;  // per-lane list capacity (uint16 group offsets), flushed when nearly full
+
+RT_DEV bool group_sign_test(const float4 S0, const float4 S1, const float4 S2, const float4 S3, V3 o, V3 d, float a) {
+    float e0, e1, e2, e3;
+#define RT_DISC_ONLY(S, E)                                             \
+    {                                                                  \
+        const float ocx = o.x - S.x;                                   \
+        const float ocy = o.y - S.y;                                   \
+        const float ocz = o.z - S.z;                                   \
+        const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;           \
+        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;  \
+        E = b * b - a * cc;                                            \
+    }
+    RT_DISC_ONLY(S0, e0)
+    RT_DISC_ONLY(S1, e1)
+    RT_DISC_ONLY(S2, e2)
+    RT_DISC_ONLY(S3, e3)
+#undef RT_DISC_ONLY
+    const int signs = __float_as_int(e0) & __float_as_int(e1) & __float_as_int(e2) & __float_as_int(e3);
+    return signs >= 0;
+}
+
+RT_DEV bool root_possible(float e, float b) { return e > 0.f && !(b > 0.f && e < b * b); }
+
+// cand: this lane's column of the wave's candidate list in LDS; slot stride is 64 entries.
+RT_DEV void scan_list_deferred(const float4* __restrict__ tab, uint32_t nPadded, V3 o, V3 d, float& tmin, int& idx, uint16_t* cand) {
+    const float a = dot3(d, d);
+    tmin = __builtin_inff();
+    idx = -1;
+    uint32_t cnt = 0;
+    uint32_t i = 0;
+    for (;;) {
+        // ---- record phase: branch-free discriminants, two groups per iteration on ping-pong registers
+        float4 A0 = tab[i], A1 = tab[i + 1], A2 = tab[i + 2], A3 = tab[i + 3];
+        bool nearlyFull = false;
+        for (; i + kScanGroup < nPadded && !nearlyFull; i += 2 * kScanGroup) {
+            const float4 B0 = tab[i + 4], B1 = tab[i + 5], B2 = tab[i + 6], B3 = tab[i + 7];
+            if (__builtin_expect(group_sign_test(A0, A1, A2, A3, o, d, a), 0)) {
+                cand[cnt * kWaveSize] = (uint16_t)i;
+                ++cnt;
+            }
+            A0 = tab[i + 8]; A1 = tab[i + 9]; A2 = tab[i + 10]; A3 = tab[i + 11];
+            if (__builtin_expect(group_sign_test(B0, B1, B2, B3, o, d, a), 0)) {
+                cand[cnt * kWaveSize] = (uint16_t)(i + 4);
+                ++cnt;
+            }
+            nearlyFull = __ballot(cnt + 2 > kCandSlots) != 0ull;
+        }
+        // ---- resolve phase: every lane evaluates its own candidates, in increasing sphere index
+        for (uint32_t it = 0; __ballot(it < cnt) != 0ull; ++it) {
+            if (it < cnt) {
+                const uint32_t g = cand[it * kWaveSize];
+                const float4 S0 = tab[g], S1 = tab[g + 1], S2 = tab[g + 2], S3 = tab[g + 3];
+                float b0, b1, b2, b3, e0, e1, e2, e3;
+#define RT_DISC(S, B, E)                                               \
+    {                                                                  \
+        const float ocx = o.x - S.x;                                   \
+        const float ocy = o.y - S.y;                                   \
+        const float ocz = o.z - S.z;                                   \
+        B = (ocx * d.x + ocy * d.y) + ocz * d.z;                       \
+        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;  \
+        E = B * B - a * cc;                                            \
+    }
+                RT_DISC(S0, b0, e0)
+                RT_DISC(S1, b1, e1)
+                RT_DISC(S2, b2, e2)
+                RT_DISC(S3, b3, e3)
+#undef RT_DISC
+                uint32_t m = (root_possible(e0, b0) ? 1u : 0u) | (root_possible(e1, b1) ? 2u : 0u) | (root_possible(e2, b2) ? 4u : 0u) |
+                             (root_possible(e3, b3) ? 8u : 0u);
+                while (m != 0u) {  // per-lane: lowest sphere first
+                    const uint32_t k = (uint32_t)__builtin_ctz(m);
+                    m &= m - 1u;
+                    const float e = k == 0u ? e0 : (k == 1u ? e1 : (k == 2u ? e2 : e3));
+                    const float b = k == 0u ? b0 : (k == 1u ? b1 : (k == 2u ? b2 : b3));
+                    const float sq = __builtin_sqrtf(e);
+                    float t = (-b - sq) / a;                 // ray-tracing.cpp:56
+                    if (!(t > 0.001f)) t = (-b + sq) / a;    // :69
+                    if (t > 0.001f && t < tmin) {
+                        tmin = t;
+                        idx = (int)(g + k);
+                    }
+                }
+            }
+        }
+        cnt = 0;
+        if (!(i + kScanGroup < nPadded)) break;
+    }
+}
+
 // --------------------------------------------------------- textures (A14), getters (A13)
 // Material record held in registers (loaded as three 16-byte reads; a by-value struct copy would
 // be demoted to scratch/LDS by the compiler).
@@ -353,11 +455,14 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
     const float4* scanTab = p.scan;
     const float* radTab = p.radius;
     const rt_material* matTab = p.mats;
+    // candidate lists first: kCandSlots x 64 uint16 per wave
+    uint16_t* candBase = reinterpret_cast<uint16_t*>(smem);
+    float4* tabBase = smem + (kThreads / kWaveSize) * (kCandSlots * kWaveSize * 2 / 16);
     if (kLds) {
         // LDS image: [n_padded] float4 scan | [n] rt_material (48 B = 3 float4) | [n] float radius
-        float4* ldsScan = smem;
-        float4* ldsMat = smem + p.n_padded;
-        float* ldsRad = reinterpret_cast<float*>(smem + (size_t)p.n_padded + (size_t)p.n * 3);
+        float4* ldsScan = tabBase;
+        float4* ldsMat = tabBase + p.n_padded;
+        float* ldsRad = reinterpret_cast<float*>(tabBase + (size_t)p.n_padded + (size_t)p.n * 3);
         const float4* gMat = reinterpret_cast<const float4*>(p.mats);
         for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) ldsScan[k] = p.scan[k];
         for (uint32_t k = threadIdx.x; k < p.n * 3; k += blockDim.x) ldsMat[k] = gMat[k];
@@ -369,6 +474,7 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
     }
 
     const uint32_t lane = threadIdx.x & (kWaveSize - 1);
+    uint16_t* cand = candBase + (threadIdx.x / kWaveSize) * (kCandSlots * kWaveSize) + lane;
     const V3 sunDir = v3(p.sun_dir[0], p.sun_dir[1], p.sun_dir[2]);
 
     // per-lane path state
@@ -433,7 +539,7 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
         float tmin = 0.f;
         int idx = -1;
         if (state != kIdle) {
-            scan_list(scanTab, p.n_padded, ro, rd, tmin, idx);
+            scan_list_deferred(scanTab, p.n_padded, ro, rd, tmin, idx, cand);
             ++nTrav;
             ++pathTrav;
         }
