@@ -91,6 +91,7 @@ struct rt_ctx {
     // tuning (env: RT_BLOCKS_PER_CU, RT_FORCE_GLOBAL_TABLES)
     uint32_t blocksPerCu = 4;
     uint32_t blockThreads = 256;
+    bool useMfma = true;  // matrix-core pre-filter for the list scan (RT_SCAN=valu disables)
     bool forceGlobal = false;
 };
 
@@ -106,8 +107,9 @@ static uint32_t RowsetLocalRows(rt_rowset rs) {
     return rows;
 }
 
-static uint32_t PaddedCount(uint32_t n) { return ((n + 7u) / 8u) * 8u + 4u; }
-static size_t LdsBytesFor(uint32_t n) { return (size_t)PaddedCount(n) * 16 + (size_t)n * (48 + 4); }
+static uint32_t PaddedCount(uint32_t n) { return ((n + 31u) / 32u) * 32u + 4u; }
+static size_t LdsBytesFor(uint32_t n) { return (size_t)PaddedCount(n) * 16 + (size_t)n * 48 + (size_t)((n + 3) / 4) * 16; }
+static size_t MfmaOpsBytesFor(uint32_t n) { return (size_t)((n + 31u) / 32u) * 4 * 64 * 4; }
 
 // Launch the megakernel over total paths described by tp.
 static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
@@ -122,24 +124,35 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     uint32_t blocks = (uint32_t)((wavesNeeded + wavesPerBlock - 1) / wavesPerBlock);
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks == 0) blocks = 1;
-    // dynamic LDS: per-wave candidate lists (16 slots x 64 lanes x 2 B) + the scene tables when they fit
-    const size_t candBytes = (size_t)wavesPerBlock * 16 * 64 * 2;
-    const size_t ldsBytes = candBytes + (useLds ? lds : 0);
-#define RT_LAUNCH(LDS, T)                                                                                                      \
+    // dynamic LDS: per-wave candidate regions + the scene tables when they fit (+ the filter operand image)
+    const size_t candBytes = (size_t)wavesPerBlock * 3328;
+    const bool mfma = useLds && ctx->useMfma && (candBytes + lds + MfmaOpsBytesFor(tp.n)) <= 160 * 1024;
+    const size_t ldsBytes = candBytes + (useLds ? lds : 0) + (mfma ? MfmaOpsBytesFor(tp.n) : 0);
+#define RT_LAUNCH(LDS, T, M)                                                                                                   \
     do {                                                                                                                      \
         if (ldsBytes > 48 * 1024)                                                                                             \
-            RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rtd::rt_trace_kernel<LDS, T>),                           \
+            RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rtd::rt_trace_kernel<LDS, T, M>),                        \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));                           \
-        hipLaunchKernelGGL((rtd::rt_trace_kernel<LDS, T>), dim3(blocks), dim3(T), ldsBytes, ctx->stream, tp);                 \
+        hipLaunchKernelGGL((rtd::rt_trace_kernel<LDS, T, M>), dim3(blocks), dim3(T), ldsBytes, ctx->stream, tp);              \
     } while (0)
-    if (useLds) {
-        if (ctx->blockThreads == 1024) RT_LAUNCH(true, 1024);
-        else if (ctx->blockThreads == 512) RT_LAUNCH(true, 512);
-        else RT_LAUNCH(true, 256);
+    if (mfma) {
+        if (ctx->blockThreads == 1024) RT_LAUNCH(true, 1024, true);
+        else if (ctx->blockThreads == 768) RT_LAUNCH(true, 768, true);
+        else if (ctx->blockThreads == 384) RT_LAUNCH(true, 384, true);
+        else if (ctx->blockThreads == 512) RT_LAUNCH(true, 512, true);
+        else RT_LAUNCH(true, 256, true);
+    } else if (useLds) {
+        if (ctx->blockThreads == 1024) RT_LAUNCH(true, 1024, false);
+        else if (ctx->blockThreads == 768) RT_LAUNCH(true, 768, false);
+        else if (ctx->blockThreads == 384) RT_LAUNCH(true, 384, false);
+        else if (ctx->blockThreads == 512) RT_LAUNCH(true, 512, false);
+        else RT_LAUNCH(true, 256, false);
     } else {
-        if (ctx->blockThreads == 1024) RT_LAUNCH(false, 1024);
-        else if (ctx->blockThreads == 512) RT_LAUNCH(false, 512);
-        else RT_LAUNCH(false, 256);
+        if (ctx->blockThreads == 1024) RT_LAUNCH(false, 1024, false);
+        else if (ctx->blockThreads == 768) RT_LAUNCH(false, 768, false);
+        else if (ctx->blockThreads == 384) RT_LAUNCH(false, 384, false);
+        else if (ctx->blockThreads == 512) RT_LAUNCH(false, 512, false);
+        else RT_LAUNCH(false, 256, false);
     }
 #undef RT_LAUNCH
     RT_HIP(hipGetLastError());
@@ -184,8 +197,14 @@ int rt_create(int device_ordinal, rt_ctx** out) {
     ctx->blocksPerCu = EnvU32("RT_BLOCKS_PER_CU", 4);
     if (ctx->blocksPerCu == 0) ctx->blocksPerCu = 1;
     ctx->forceGlobal = EnvU32("RT_FORCE_GLOBAL_TABLES", 0) != 0;
+    {
+        const char* scan = std::getenv("RT_SCAN");
+        ctx->useMfma = !(scan && std::strcmp(scan, "valu") == 0);
+    }
     ctx->blockThreads = EnvU32("RT_BLOCK_THREADS", 256);
-    if (ctx->blockThreads != 256 && ctx->blockThreads != 512 && ctx->blockThreads != 1024) ctx->blockThreads = 256;
+    if (ctx->blockThreads != 256 && ctx->blockThreads != 384 && ctx->blockThreads != 512 && ctx->blockThreads != 768 &&
+        ctx->blockThreads != 1024)
+        ctx->blockThreads = 256;
     int rc = ctx->queue.Reserve(1);
     if (rc == RT_OK) rc = ctx->counters.Reserve(2);
     if (rc != RT_OK) {

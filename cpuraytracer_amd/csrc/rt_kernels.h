@@ -44,7 +44,7 @@ struct TraceParams {
     const float* radius;       // [n]
     const rt_material* mats;   // [n]
     uint32_t n;
-    uint32_t n_padded;         // roundup(n, 8) + 4
+    uint32_t n_padded;         // roundup(n, 32) + 4
     float cam_o[3], cam_x[3], cam_y[3], cam_oip[3];
     float aperture, focal;
     float sun_dir[3], sun_rad[3];  // sun_rad = luminance * colour (light.cpp:27, left factor)
@@ -226,6 +226,44 @@ RT_DEV bool group_sign_test(const float4 S0, const float4 S1, const float4 S2, c
 
 RT_DEV bool root_possible(float e, float b) { return e > 0.f && !(b > 0.f && e < b * b); }
 
+// Exact evaluation of one recorded group (four consecutive spheres starting at g) for this lane's ray:
+// Sphere::Intersect's arithmetic (ray-tracing.cpp:44-71) and the closest-hit update.  Smaller t wins;
+// equal t keeps the lower sphere index whatever order groups are resolved in.
+RT_DEV void resolve_group(const float4* __restrict__ tab, uint32_t g, V3 o, V3 d, float a, float& tmin, int& idx) {
+    const float4 S0 = tab[g], S1 = tab[g + 1], S2 = tab[g + 2], S3 = tab[g + 3];
+    float b0, b1, b2, b3, e0, e1, e2, e3;
+#define RT_DISC(S, B, E)                                               \
+    {                                                                  \
+        const float ocx = o.x - S.x;                                   \
+        const float ocy = o.y - S.y;                                   \
+        const float ocz = o.z - S.z;                                   \
+        B = (ocx * d.x + ocy * d.y) + ocz * d.z;                       \
+        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;  \
+        E = B * B - a * cc;                                            \
+    }
+    RT_DISC(S0, b0, e0)
+    RT_DISC(S1, b1, e1)
+    RT_DISC(S2, b2, e2)
+    RT_DISC(S3, b3, e3)
+#undef RT_DISC
+    uint32_t m = (root_possible(e0, b0) ? 1u : 0u) | (root_possible(e1, b1) ? 2u : 0u) | (root_possible(e2, b2) ? 4u : 0u) |
+                 (root_possible(e3, b3) ? 8u : 0u);
+    while (m != 0u) {  // per-lane loop: all lanes evaluate one of their own candidates per iteration
+        const uint32_t k = (uint32_t)__builtin_ctz(m);
+        m &= m - 1u;
+        const float e = k == 0u ? e0 : (k == 1u ? e1 : (k == 2u ? e2 : e3));
+        const float b = k == 0u ? b0 : (k == 1u ? b1 : (k == 2u ? b2 : b3));
+        const float sq = __builtin_sqrtf(e);
+        float t = (-b - sq) / a;               // ray-tracing.cpp:56
+        if (!(t > 0.001f)) t = (-b + sq) / a;  // :69
+        const int cand = (int)(g + k);
+        if (t > 0.001f && (t < tmin || (t == tmin && cand < idx))) {
+            tmin = t;
+            idx = cand;
+        }
+    }
+}
+
 // cand: this lane's column of the wave's candidate list in LDS; slot stride is 64 entries.
 RT_DEV void scan_list_deferred(const float4* __restrict__ tab, uint32_t nPadded, V3 o, V3 d, float& tmin, int& idx, uint16_t* cand) {
     const float a = dot3(d, d);
@@ -254,41 +292,137 @@ RT_DEV void scan_list_deferred(const float4* __restrict__ tab, uint32_t nPadded,
         for (uint32_t it = 0; __ballot(it < cnt) != 0ull; ++it) {
             if (it < cnt) {
                 const uint32_t g = cand[it * kWaveSize];
-                const float4 S0 = tab[g], S1 = tab[g + 1], S2 = tab[g + 2], S3 = tab[g + 3];
-                float b0, b1, b2, b3, e0, e1, e2, e3;
-#define RT_DISC(S, B, E)                                               \
-    {                                                                  \
-        const float ocx = o.x - S.x;                                   \
-        const float ocy = o.y - S.y;                                   \
-        const float ocz = o.z - S.z;                                   \
-        B = (ocx * d.x + ocy * d.y) + ocz * d.z;                       \
-        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;  \
-        E = B * B - a * cc;                                            \
-    }
-                RT_DISC(S0, b0, e0)
-                RT_DISC(S1, b1, e1)
-                RT_DISC(S2, b2, e2)
-                RT_DISC(S3, b3, e3)
-#undef RT_DISC
-                uint32_t m = (root_possible(e0, b0) ? 1u : 0u) | (root_possible(e1, b1) ? 2u : 0u) | (root_possible(e2, b2) ? 4u : 0u) |
-                             (root_possible(e3, b3) ? 8u : 0u);
-                while (m != 0u) {  // per-lane: lowest sphere first
-                    const uint32_t k = (uint32_t)__builtin_ctz(m);
-                    m &= m - 1u;
-                    const float e = k == 0u ? e0 : (k == 1u ? e1 : (k == 2u ? e2 : e3));
-                    const float b = k == 0u ? b0 : (k == 1u ? b1 : (k == 2u ? b2 : b3));
-                    const float sq = __builtin_sqrtf(e);
-                    float t = (-b - sq) / a;                 // ray-tracing.cpp:56
-                    if (!(t > 0.001f)) t = (-b + sq) / a;    // :69
-                    if (t > 0.001f && t < tmin) {
-                        tmin = t;
-                        idx = (int)(g + k);
-                    }
-                }
+                resolve_group(tab, g, o, d, a, tmin, idx);
             }
         }
         cnt = 0;
         if (!(i + kScanGroup < nPadded)) break;
+    }
+}
+
+// ------------------------------------------------ list scan with a matrix-core pre-filter
+// The all-pairs test "which of these 64 rays can hit which of these N spheres" IS a dense
+// contraction: b = d.(o - c) = [d, d.o].[-c, 1] and a*cc = a|o|^2 + [-2a o, a].[c, |c|^2 - r^2] are
+// K = 4 inner products between a per-ray and a per-sphere vector.  gfx950's v_mfma_f32_32x32x2_f32
+// computes them as exact f32 FMA chains at 64 flop/clk/SIMD on the matrix pipe, which runs beside the
+// VALU — against 17 VALU instructions per sphere for the reference-order arithmetic.  The MFMA
+// result is NOT the reference's rounding, so it is used only as a conservative FILTER:
+//     F = b~^2 - a*cc~ + M,   M = K eps a (2|o|^2 + 2|c|^2 + r^2),  K = 64, eps = 2^-24
+// M exceeds the sum of the rounding-error bounds of the reference-order discriminant and of the
+// filter (<= 46 eps a ((|o|+|c|)^2 + r^2)), so disc_ref > 0 implies F > 0: no sphere
+// the reference would hit is ever dropped.  Groups with a non-negative F are recorded per ray and then
+// resolved EXACTLY by resolve_group (reference-order VALU arithmetic), so the image is bit-identical
+// to the pure-VALU scan and to the oracle; the filter only decides how much exact work is skipped.
+//
+// Tile mapping (32 spheres x 32 rays per MFMA, spheres = rows/A, rays = columns/B): lane l supplies
+// A[l&31][l>>5] and B[l>>5][l&31]; it receives, for ray column l&31, the 16 sphere rows
+// (r&3) + 8(r>>2) + 4(l>>5) — i.e. registers 4g..4g+3 are one aligned group of four consecutive
+// spheres.  Rays 0-31 and 32-63 are two column tiles; lane l and lane l^32 split each ray's spheres,
+// so every ray has two producer lanes, each with its own sub-list and register counter (no atomics).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr uint32_t kMfmaSlots = 12;                                    // entries per (ray, half) sub-list
+constexpr uint32_t kWaveCandBytes = 64 * 2 * kMfmaSlots * 2 + 128 * 2;  // lists + counts = 3328 B per wave
+constexpr float kMarginRel = 64.f * 5.9604645e-8f;                     // K * eps
+
+// Sphere operand image for the filter, built once per workgroup: ops[tile][4][64] floats.
+RT_DEV void build_mfma_operands(const float4* __restrict__ scan, uint32_t nReal, uint32_t nTiles, float* __restrict__ ops, uint32_t tid,
+                                uint32_t nthreads) {
+    for (uint32_t e = tid; e < nTiles * 64; e += nthreads) {
+        const uint32_t t = e >> 6, l = e & 63, h = l >> 5;
+        const uint32_t si = t * 32 + (l & 31);
+        float4 S = make_float4(0.f, 0.f, 0.f, -1.f);
+        if (si < nReal) S = scan[si];
+        float w = 1e30f;  // padding rows: a*cc~ = +huge => F < 0, never recorded
+        if (S.w >= 0.f) {
+            const float c2 = (S.x * S.x + S.y * S.y) + S.z * S.z;
+            w = (c2 - S.w) - kMarginRel * (2.f * c2 + S.w);
+        }
+        float* o = ops + (size_t)t * 256 + l;
+        o[0] = h == 0 ? -S.x : -S.y;
+        o[64] = h == 0 ? -S.z : 1.f;
+        o[128] = h == 0 ? S.x : S.y;
+        o[192] = h == 0 ? S.z : w;
+    }
+}
+
+RT_DEV void mfma_post(const f32x16& Tb, const f32x16& Tg, float cray, uint16_t* list, uint32_t& cnt, uint32_t base) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float f0 = __builtin_fmaf(Tb[4 * g + 0], Tb[4 * g + 0], -(Tg[4 * g + 0] + cray));
+        const float f1 = __builtin_fmaf(Tb[4 * g + 1], Tb[4 * g + 1], -(Tg[4 * g + 1] + cray));
+        const float f2 = __builtin_fmaf(Tb[4 * g + 2], Tb[4 * g + 2], -(Tg[4 * g + 2] + cray));
+        const float f3 = __builtin_fmaf(Tb[4 * g + 3], Tb[4 * g + 3], -(Tg[4 * g + 3] + cray));
+        const int signs = __float_as_int(f0) & __float_as_int(f1) & __float_as_int(f2) & __float_as_int(f3);
+        if (__builtin_expect(signs >= 0, 0)) {
+            list[cnt] = (uint16_t)(base + 8u * (uint32_t)g);
+            ++cnt;
+        }
+    }
+}
+
+RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float* __restrict__ ops, uint32_t nTiles, V3 o, V3 d, bool live, float& tmin,
+                           int& idx, uint16_t* waveCand, uint32_t lane) {
+    const float a = dot3(d, d);
+    tmin = __builtin_inff();
+    idx = -1;
+    const uint32_t half = lane >> 5, col = lane & 31u;
+    // per-ray operand values (filter arithmetic: any rounding, the margin covers it)
+    const float dO = dot3(d, o);
+    const float m2a = -2.f * a;
+    const float gx = m2a * o.x, gy = m2a * o.y, gz = m2a * o.z;
+    // a dead ray's a*cc~ is made huge so that nothing is ever recorded for it
+    const float cr = live ? (a * dot3(o, o)) * (1.f - 2.f * kMarginRel) : 1e30f;
+    // the other half-wave's ray (lane ^ 32)
+    const float pdx = __shfl_xor(d.x, 32), pdy = __shfl_xor(d.y, 32), pdz = __shfl_xor(d.z, 32), pdO = __shfl_xor(dO, 32);
+    const float pgx = __shfl_xor(gx, 32), pgy = __shfl_xor(gy, 32), pgz = __shfl_xor(gz, 32), pa = __shfl_xor(a, 32);
+    const float pcr = __shfl_xor(cr, 32);
+    const bool lo = half == 0u;
+    // B operands: tile 0 = rays 0..31 (owner lanes 0..31), tile 1 = rays 32..63 (owner lanes 32..63)
+    const float bb00 = lo ? d.x : pdy, bb01 = lo ? d.z : pdO;   // tile 0: k = 0,2 from the owner, k = 1,3 from lane-32
+    const float bb10 = lo ? pdx : d.y, bb11 = lo ? pdz : dO;    // tile 1
+    const float bg00 = lo ? gx : pgy, bg01 = lo ? gz : pa;
+    const float bg10 = lo ? pgx : gy, bg11 = lo ? pgz : a;
+    const float cr0 = lo ? cr : pcr, cr1 = lo ? pcr : cr;
+    uint16_t* lists = waveCand;
+    uint16_t* counts = waveCand + 64 * 2 * kMfmaSlots;
+    uint16_t* list0 = lists + ((col * 2u + half) * kMfmaSlots);
+    uint16_t* list1 = lists + (((col + 32u) * 2u + half) * kMfmaSlots);
+    uint32_t cnt0 = 0, cnt1 = 0;
+    uint32_t s = 0;
+    for (;;) {
+        bool nearlyFull = false;
+        for (; s < nTiles && !nearlyFull; ++s) {
+            const float* op = ops + (size_t)s * 256 + lane;
+            const float ab1 = op[0], ab2 = op[64], ag1 = op[128], ag2 = op[192];
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 Tb0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab1, bb00, zero, 0, 0, 0);
+            f32x16 Tg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag1, bg00, zero, 0, 0, 0);
+            f32x16 Tb1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab1, bb10, zero, 0, 0, 0);
+            f32x16 Tg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag1, bg10, zero, 0, 0, 0);
+            Tb0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab2, bb01, Tb0, 0, 0, 0);
+            Tg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag2, bg01, Tg0, 0, 0, 0);
+            Tb1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab2, bb11, Tb1, 0, 0, 0);
+            Tg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag2, bg11, Tg1, 0, 0, 0);
+            const uint32_t base = 32u * s + 4u * half;
+            mfma_post(Tb0, Tg0, cr0, list0, cnt0, base);
+            mfma_post(Tb1, Tg1, cr1, list1, cnt1, base);
+            nearlyFull = __ballot((cnt0 > cnt1 ? cnt0 : cnt1) + 4u > kMfmaSlots) != 0ull;
+        }
+        // publish the producers' counts, then every lane resolves its OWN ray's two sub-lists
+        counts[col * 2u + half] = (uint16_t)cnt0;
+        counts[(col + 32u) * 2u + half] = (uint16_t)cnt1;
+        const uint32_t c0 = counts[lane * 2u], c1 = counts[lane * 2u + 1u];
+        const uint32_t tot = c0 + c1;
+        const uint16_t* mine = lists + lane * 2u * kMfmaSlots;
+        for (uint32_t it = 0; __ballot(it < tot) != 0ull; ++it) {
+            if (it < tot) {
+                const uint32_t g = it < c0 ? mine[it] : mine[kMfmaSlots + (it - c0)];
+                resolve_group(tab, g, o, d, a, tmin, idx);
+            }
+        }
+        cnt0 = 0;
+        cnt1 = 0;
+        if (s >= nTiles) break;
     }
 }
 
@@ -449,15 +583,17 @@ enum : uint32_t { kIdle = 0u, kNeedClosest = 1u, kNeedShadow = 2u };
 // never synchronise with each other after the LDS staging barrier, and every wave's loop ends when
 // the (bounded, monotonically consumed) queue is exhausted and its at most 64 paths of at most
 // max_depth+1 segments have finished.
-template <bool kLds, int kThreads>
+template <bool kLds, int kThreads, bool kMfma>
 __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p) {
     extern __shared__ float4 smem[];
     const float4* scanTab = p.scan;
     const float* radTab = p.radius;
     const rt_material* matTab = p.mats;
-    // candidate lists first: kCandSlots x 64 uint16 per wave
+    // per-wave candidate regions first (kWaveCandBytes each; the VALU scan uses the first 2 KiB of its region)
     uint16_t* candBase = reinterpret_cast<uint16_t*>(smem);
-    float4* tabBase = smem + (kThreads / kWaveSize) * (kCandSlots * kWaveSize * 2 / 16);
+    float4* tabBase = smem + (kThreads / kWaveSize) * (kWaveCandBytes / 16);
+    const float* mfmaOps = nullptr;
+    const uint32_t nTiles = (p.n + 31u) / 32u;
     if (kLds) {
         // LDS image: [n_padded] float4 scan | [n] rt_material (48 B = 3 float4) | [n] float radius
         float4* ldsScan = tabBase;
@@ -467,6 +603,12 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
         for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) ldsScan[k] = p.scan[k];
         for (uint32_t k = threadIdx.x; k < p.n * 3; k += blockDim.x) ldsMat[k] = gMat[k];
         for (uint32_t k = threadIdx.x; k < p.n; k += blockDim.x) ldsRad[k] = p.radius[k];
+        if (kMfma) {
+            // filter operand image after the radii (16-byte aligned): nTiles x 4 x 64 floats
+            float* ldsOps = reinterpret_cast<float*>(tabBase + (size_t)p.n_padded + (size_t)p.n * 3 + (p.n + 3u) / 4u);
+            build_mfma_operands(p.scan, p.n, nTiles, ldsOps, threadIdx.x, blockDim.x);
+            mfmaOps = ldsOps;
+        }
         __syncthreads();
         scanTab = ldsScan;
         radTab = ldsRad;
@@ -474,7 +616,8 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
     }
 
     const uint32_t lane = threadIdx.x & (kWaveSize - 1);
-    uint16_t* cand = candBase + (threadIdx.x / kWaveSize) * (kCandSlots * kWaveSize) + lane;
+    uint16_t* waveCand = candBase + (threadIdx.x / kWaveSize) * (kWaveCandBytes / 2);
+    uint16_t* cand = waveCand + lane;
     const V3 sunDir = v3(p.sun_dir[0], p.sun_dir[1], p.sun_dir[2]);
 
     // per-lane path state
@@ -538,8 +681,14 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
         // ------------------------------------------------ one list scan for every live lane
         float tmin = 0.f;
         int idx = -1;
-        if (state != kIdle) {
+        if (kMfma) {
+            // every lane takes part: lane l also supplies operands for, and filters half the spheres of,
+            // the ray owned by lane l^32, whether or not its own ray is live
+            scan_list_mfma(scanTab, mfmaOps, nTiles, ro, rd, state != kIdle, tmin, idx, waveCand, lane);
+        } else if (state != kIdle) {
             scan_list_deferred(scanTab, p.n_padded, ro, rd, tmin, idx, cand);
+        }
+        if (state != kIdle) {
             ++nTrav;
             ++pathTrav;
         }

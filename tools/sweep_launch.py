@@ -14,10 +14,12 @@ for _ in range(3):
     st = r.render(1200, 800, 1, 1 + spp, 50, 1)
     ms = st.ms_render + st.ms_accumulate
     best = ms if best is None or ms < best else best
-print(json.dumps({"threads": os.environ.get("RT_BLOCK_THREADS"), "blocks_per_cu": os.environ.get("RT_BLOCKS_PER_CU"), "spp": spp,
+print(json.dumps({"scan": os.environ.get("RT_SCAN", "mfma"), "threads": os.environ.get("RT_BLOCK_THREADS"), "blocks_per_cu": os.environ.get("RT_BLOCKS_PER_CU"), "spp": spp,
                   "ms": best, "ms_trace": st.ms_render, "ms_acc": st.ms_accumulate, "Msamples_per_s": st.samples / best / 1e3}))
 ''' % ROOT
-for threads, bpcs in ((256, (2, 3, 4)), (512, (1, 2, 3)), (1024, (1, 2))):
+CONFIGS = os.environ.get("SWEEP_CONFIGS")
+cfgs = [tuple(int(v) for v in c.split("x")) for c in CONFIGS.split(",")] if CONFIGS else None
+for threads, bpcs in ([(t, (b,)) for t, b in cfgs] if cfgs else ((256, (2, 3, 4)), (512, (1, 2, 3)), (1024, (1, 2)))):
     for bpc in bpcs:
         env = dict(os.environ, RT_BLOCK_THREADS=str(threads), RT_BLOCKS_PER_CU=str(bpc))
         p = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
