@@ -3,6 +3,8 @@
 // point that needs the device fails with RT_ERR_NO_DEVICE / RT_ERR_HIP when it is absent.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -71,7 +73,8 @@ struct rt_ctx {
     // scene
     bool hasScene = false;
     uint32_t n = 0;
-    DevBuf<float4> scan;
+    DevBuf<float4> scan, bounds;
+    DevBuf<uint32_t> orig;
     DevBuf<float> radius;
     DevBuf<rt_material> mats;
     rtd::TraceParams base{};  // scene part filled at upload
@@ -107,14 +110,103 @@ static uint32_t RowsetLocalRows(rt_rowset rs) {
     return rows;
 }
 
-static uint32_t PaddedCount(uint32_t n) { return ((n + 31u) / 32u) * 32u + 4u; }
-static size_t LdsBytesFor(uint32_t n) { return (size_t)PaddedCount(n) * 16 + (size_t)n * 48 + (size_t)((n + 3) / 4) * 16; }
-static size_t MfmaOpsBytesFor(uint32_t n) { return (size_t)((n + 31u) / 32u) * 4 * 64 * 4; }
+// ---------------------------------------------------------------------------------- scene layout
+// Clustered storage for the scan (rt_kernels.h): spheres split by a k-d median tree into groups of four, unusually
+// large spheres alone, every group with a conservative bounding sphere for the matrix-core filter.
+struct SceneLayout {
+    std::vector<float4> scan;     // 4 * nGroups + 4 entries
+    std::vector<uint32_t> orig;   // same length
+    std::vector<float4> bounds;   // nGroups
+    uint32_t nGroups = 0;
+};
+
+static void BuildLayout(const rt_sphere* sp, uint32_t n, SceneLayout& L) {
+    std::vector<float> radii(n);
+    for (uint32_t k = 0; k < n; ++k) radii[k] = sp[k].r;
+    std::vector<float> sorted = radii;
+    std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+    const float median = sorted[n / 2];
+    std::vector<uint32_t> big, small;
+    for (uint32_t k = 0; k < n; ++k) (radii[k] > 4.f * median ? big : small).push_back(k);
+    // k-d median split down to leaves of four: compact, balanced groups (Morton chunks of a jittered grid
+    // have 3x the summed R^2 and twice the filter candidates; tools/cluster_eval.py)
+    std::vector<std::vector<uint32_t>> groups;
+    for (uint32_t k : big) groups.push_back({k});
+    std::vector<std::pair<size_t, size_t>> stack;  // [begin, end) ranges of `small`
+    if (!small.empty()) stack.push_back({0, small.size()});
+    while (!stack.empty()) {
+        const auto [b, e] = stack.back();
+        stack.pop_back();
+        if (e - b <= 4) {
+            groups.push_back(std::vector<uint32_t>(small.begin() + b, small.begin() + e));
+            continue;
+        }
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t k = b; k < e; ++k) {
+            const float c[3] = {sp[small[k]].cx, sp[small[k]].cy, sp[small[k]].cz};
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::min(lo[a], c[a]);
+                hi[a] = std::max(hi[a], c[a]);
+            }
+        }
+        int ax = 0;
+        if (hi[1] - lo[1] > hi[ax] - lo[ax]) ax = 1;
+        if (hi[2] - lo[2] > hi[ax] - lo[ax]) ax = 2;
+        std::stable_sort(small.begin() + b, small.begin() + e, [&](uint32_t x, uint32_t y) {
+            const float cx[3] = {sp[x].cx, sp[x].cy, sp[x].cz}, cy[3] = {sp[y].cx, sp[y].cy, sp[y].cz};
+            return cx[ax] < cy[ax];
+        });
+        size_t half = ((e - b) / 2 + 3) / 4 * 4;  // left part a multiple of four
+        if (half >= e - b) half = (e - b) / 2;
+        stack.push_back({b + half, e});
+        stack.push_back({b, b + half});
+    }
+    if (groups.size() & 1u) groups.push_back({});  // the VALU scan walks two groups per iteration
+    L.nGroups = (uint32_t)groups.size();
+    const float4 never = make_float4(0.f, 0.f, 0.f, -1e30f);  // r*r = -1e30: discriminant negative for any ray
+    L.scan.assign((size_t)L.nGroups * 4 + 4, never);
+    L.orig.assign((size_t)L.nGroups * 4 + 4, 0xffffffffu);
+    L.bounds.assign(L.nGroups, make_float4(0.f, 0.f, 0.f, 1e30f));
+    const double kEps = 2048.0 * 5.9604644775390625e-08;  // K * eps, K = 2048 (rt_kernels.h kMarginRel)
+    for (uint32_t gi = 0; gi < L.nGroups; ++gi) {
+        const auto& g = groups[gi];
+        if (g.empty()) continue;
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (uint32_t k : g) {
+            const double c[3] = {sp[k].cx, sp[k].cy, sp[k].cz};
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::min(lo[a], c[a]);
+                hi[a] = std::max(hi[a], c[a]);
+            }
+        }
+        // the bound centre is the FLOAT the device will use, so its rounding is inside s_i below
+        const float Cf[3] = {(float)(0.5 * (lo[0] + hi[0])), (float)(0.5 * (lo[1] + hi[1])), (float)(0.5 * (lo[2] + hi[2]))};
+        double R = 0, smax = 0;
+        for (size_t m = 0; m < g.size(); ++m) {
+            const uint32_t k = g[m];
+            const double dx = sp[k].cx - (double)Cf[0], dy = sp[k].cy - (double)Cf[1], dz = sp[k].cz - (double)Cf[2];
+            const double si = std::sqrt(dx * dx + dy * dy + dz * dz);
+            smax = std::max(smax, si);
+            R = std::max(R, si + (double)sp[k].r);
+            // radius * radius is the float product Sphere::Intersect forms per call (ray-tracing.cpp:48)
+            L.scan[(size_t)gi * 4 + m] = make_float4(sp[k].cx, sp[k].cy, sp[k].cz, sp[k].r * sp[k].r);
+            L.orig[(size_t)gi * 4 + m] = k;
+        }
+        const double C2 = (double)Cf[0] * Cf[0] + (double)Cf[1] * Cf[1] + (double)Cf[2] * Cf[2];
+        const double Cn = std::sqrt(C2);
+        const double Rf2 = R * R * (1.0 + 1e-5) + 0.01 * smax * smax + kEps * (2.0 * (Cn + R) * (Cn + R) + R * R);
+        float w = (float)(C2 - Rf2);
+        w = std::nextafterf(std::nextafterf(w, -INFINITY), -INFINITY);  // err towards "more candidates"
+        L.bounds[gi] = make_float4(Cf[0], Cf[1], Cf[2], w);
+    }
+}
+static size_t LdsBytesFor(uint32_t n, uint32_t nPadded) { return (size_t)nPadded * (16 + 4) + (size_t)n * 48 + (size_t)((n + 3) / 4) * 16; }
+static size_t MfmaOpsBytesFor(uint32_t nGroups) { return (size_t)((nGroups + 31u) / 32u) * 4 * 64 * 4; }
 
 // Launch the megakernel over total paths described by tp.
 static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     RT_HIP(hipMemsetAsync(ctx->queue.ptr, 0, sizeof(uint32_t), ctx->stream));
-    const size_t lds = LdsBytesFor(tp.n);
+    const size_t lds = LdsBytesFor(tp.n, tp.n_padded);
     const bool useLds = !ctx->forceGlobal && lds <= 48 * 1024 && tp.n_padded < 65536;
     if (tp.n_padded >= 65536) return Fail(RT_ERR_INVALID_ARG, "scenes beyond 65,000 spheres are not supported by the 16-bit candidate lists");
     const uint32_t maxBlocks = (uint32_t)ctx->cuCount * ctx->blocksPerCu;
@@ -125,9 +217,9 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks == 0) blocks = 1;
     // dynamic LDS: per-wave candidate regions + the scene tables when they fit (+ the filter operand image)
-    const size_t candBytes = (size_t)wavesPerBlock * 3328;
-    const bool mfma = useLds && ctx->useMfma && (candBytes + lds + MfmaOpsBytesFor(tp.n)) <= 160 * 1024;
-    const size_t ldsBytes = candBytes + (useLds ? lds : 0) + (mfma ? MfmaOpsBytesFor(tp.n) : 0);
+    const size_t candBytes = (size_t)wavesPerBlock * 3840;
+    const bool mfma = useLds && ctx->useMfma && (candBytes + lds + MfmaOpsBytesFor(tp.n_groups)) <= 160 * 1024;
+    const size_t ldsBytes = candBytes + (useLds ? lds : 0) + (mfma ? MfmaOpsBytesFor(tp.n_groups) : 0);
 #define RT_LAUNCH(LDS, T, M)                                                                                                   \
     do {                                                                                                                      \
         if (ldsBytes > 48 * 1024)                                                                                             \
@@ -221,6 +313,8 @@ void rt_destroy(rt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->scan.Release();
+    ctx->orig.Release();
+    ctx->bounds.Release();
     ctx->radius.Release();
     ctx->mats.Release();
     ctx->hdr.Release();
@@ -254,26 +348,29 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
         return Fail(RT_ERR_INVALID_ARG, "rt_scene_upload: null pointer or empty scene");
     RT_HIP(hipSetDevice(ctx->device));
     int rc;
-    const uint32_t nPad = PaddedCount(n);
+    SceneLayout L;
+    BuildLayout(spheres, n, L);
+    const uint32_t nPad = (uint32_t)L.scan.size();
     if ((rc = ctx->scan.Reserve(nPad)) != RT_OK) return rc;
+    if ((rc = ctx->orig.Reserve(nPad)) != RT_OK) return rc;
+    if ((rc = ctx->bounds.Reserve(L.nGroups)) != RT_OK) return rc;
     if ((rc = ctx->radius.Reserve(n)) != RT_OK) return rc;
     if ((rc = ctx->mats.Reserve(n)) != RT_OK) return rc;
-    // padding entries can never be hit: r*r = -1e30 makes the discriminant negative for any ray
-    std::vector<float4> scan(nPad, make_float4(0.f, 0.f, 0.f, -1e30f));
     std::vector<float> rad(n);
-    for (uint32_t k = 0; k < n; ++k) {
-        // radius * radius is the float product Sphere::Intersect forms per call (ray-tracing.cpp:48)
-        scan[k] = make_float4(spheres[k].cx, spheres[k].cy, spheres[k].cz, spheres[k].r * spheres[k].r);
-        rad[k] = spheres[k].r;
-    }
+    for (uint32_t k = 0; k < n; ++k) rad[k] = spheres[k].r;
     RT_HIP(hipStreamSynchronize(ctx->stream));
-    RT_HIP(hipMemcpy(ctx->scan.ptr, scan.data(), nPad * sizeof(float4), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->scan.ptr, L.scan.data(), nPad * sizeof(float4), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->orig.ptr, L.orig.data(), nPad * sizeof(uint32_t), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->bounds.ptr, L.bounds.data(), L.nGroups * sizeof(float4), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->radius.ptr, rad.data(), n * sizeof(float), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->mats.ptr, materials, n * sizeof(rt_material), hipMemcpyHostToDevice));
 
     rtd::TraceParams& b = ctx->base;
     b = rtd::TraceParams{};
     b.scan = ctx->scan.ptr;
+    b.orig = ctx->orig.ptr;
+    b.bounds = ctx->bounds.ptr;
+    b.n_groups = L.nGroups;
     b.radius = ctx->radius.ptr;
     b.mats = ctx->mats.ptr;
     b.n = n;

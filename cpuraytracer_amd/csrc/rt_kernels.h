@@ -40,11 +40,17 @@ constexpr uint32_t kQueueBlock = 256;  // paths a wave takes from the global que
 
 struct TraceParams {
     // scene
-    const float4* scan;        // [n_padded] cx, cy, cz, r*r (padding: never-hit entries)
-    const float* radius;       // [n]
-    const rt_material* mats;   // [n]
-    uint32_t n;
-    uint32_t n_padded;         // roundup(n, 32) + 4
+    // Spheres are stored CLUSTERED: groups of four spatially close spheres (Morton order; large spheres alone),
+    // each group with a conservative bounding sphere.  Results do not depend on the order: the closest-hit
+    // update breaks ties by the ORIGINAL list index (orig[]).
+    const float4* scan;        // [n_padded] cx, cy, cz, r*r in clustered order (padding: never-hit entries, r*r = -1e30)
+    const uint32_t* orig;      // [n_padded] original list index of each entry (0xffffffff for padding)
+    const float4* bounds;      // [n_groups] group bound for the filter: Cx, Cy, Cz, |C|^2 - Rf^2
+    const float* radius;       // [n] by original index
+    const rt_material* mats;   // [n] by original index
+    uint32_t n;                // real spheres
+    uint32_t n_groups;         // groups of four entries (even)
+    uint32_t n_padded;         // 4 * n_groups + 4
     float cam_o[3], cam_x[3], cam_y[3], cam_oip[3];
     float aperture, focal;
     float sun_dir[3], sun_rad[3];  // sun_rad = luminance * colour (light.cpp:27, left factor)
@@ -136,57 +142,34 @@ RT_DEV void gen_primary_ray(const TraceParams& p, uint32_t i, uint32_t j, uint32
 // of eight plus one group with never-hit entries (r*r = -1e30 => disc < 0).
 constexpr uint32_t kScanGroup = 4;
 
-RT_DEV void root_test(float disc, float b, float a, uint32_t i, float& tmin, int& idx) {
+// Reference-order root evaluation for entry i (ray-tracing.cpp:54-71); ties keep the lower ORIGINAL index.
+RT_DEV void root_test(float disc, float b, float a, uint32_t i, const uint32_t* __restrict__ orig, float& tmin, int& idx) {
     if (disc > 0.f) {  // ray-tracing.cpp:54
         const float sq = __builtin_sqrtf(disc);
-        float t = (-b - sq) / a;                      // :56
-        if (!(t > 0.001f)) t = (-b + sq) / a;         // :58, :69-71 (bias 0.001, :52)
-        if (t > 0.001f && t < tmin) {
+        float t = (-b - sq) / a;                // :56
+        if (!(t > 0.001f)) t = (-b + sq) / a;   // :58, :69-71 (bias 0.001, :52)
+        if (t > 0.001f && (t < tmin || (t == tmin && idx >= 0 && orig[i] < orig[idx]))) {
             tmin = t;
             idx = (int)i;
         }
     }
 }
 
-// One group: discriminants of four spheres, then the guarded root evaluation.
-RT_DEV void scan_group(const float4 S0, const float4 S1, const float4 S2, const float4 S3, uint32_t i, V3 o, V3 d, float a, float& tmin,
-                       int& idx) {
-    float b0, b1, b2, b3, e0, e1, e2, e3;
-#define RT_DISC(S, B, E)                                               \
-    {                                                                  \
-        const float ocx = o.x - S.x;                                   \
-        const float ocy = o.y - S.y;                                   \
-        const float ocz = o.z - S.z;                                   \
-        B = (ocx * d.x + ocy * d.y) + ocz * d.z;                       \
-        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;  \
-        E = B * B - a * cc;                                            \
-    }
-    RT_DISC(S0, b0, e0)
-    RT_DISC(S1, b1, e1)
-    RT_DISC(S2, b2, e2)
-    RT_DISC(S3, b3, e3)
-#undef RT_DISC
-    const int signs = __float_as_int(e0) & __float_as_int(e1) & __float_as_int(e2) & __float_as_int(e3);
-    if (__builtin_expect(signs >= 0, 0)) {
-        root_test(e0, b0, a, i + 0, tmin, idx);
-        root_test(e1, b1, a, i + 1, tmin, idx);
-        root_test(e2, b2, a, i + 2, tmin, idx);
-        root_test(e3, b3, a, i + 3, tmin, idx);
-    }
-}
-
-// nPadded = roundup(n, 8) + 4: two groups per iteration on ping-pong register sets (no copies);
-// the final group is padding and is only ever prefetched.
-RT_DEV void scan_list(const float4* __restrict__ tab, uint32_t nPadded, V3 o, V3 d, float& tmin, int& idx) {
+// Plain sequential scan over every entry (unit-test kernel; the megakernel uses the filtered scans below).
+RT_DEV void scan_list(const float4* __restrict__ tab, const uint32_t* __restrict__ orig, uint32_t nEntries, V3 o, V3 d, float& tmin,
+                      int& idx) {
     const float a = dot3(d, d);
     tmin = __builtin_inff();
     idx = -1;
-    float4 A0 = tab[0], A1 = tab[1], A2 = tab[2], A3 = tab[3];
-    for (uint32_t i = 0; i + kScanGroup < nPadded; i += 2 * kScanGroup) {
-        const float4 B0 = tab[i + 4], B1 = tab[i + 5], B2 = tab[i + 6], B3 = tab[i + 7];
-        scan_group(A0, A1, A2, A3, i, o, d, a, tmin, idx);
-        A0 = tab[i + 8]; A1 = tab[i + 9]; A2 = tab[i + 10]; A3 = tab[i + 11];
-        scan_group(B0, B1, B2, B3, i + 4, o, d, a, tmin, idx);
+    for (uint32_t i = 0; i < nEntries; ++i) {
+        const float4 S = tab[i];
+        const float ocx = o.x - S.x;
+        const float ocy = o.y - S.y;
+        const float ocz = o.z - S.z;
+        const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
+        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;
+        const float disc = b * b - a * cc;
+        root_test(disc, b, a, i, orig, tmin, idx);
     }
 }
 
@@ -228,8 +211,9 @@ RT_DEV bool root_possible(float e, float b) { return e > 0.f && !(b > 0.f && e <
 
 // Exact evaluation of one recorded group (four consecutive spheres starting at g) for this lane's ray:
 // Sphere::Intersect's arithmetic (ray-tracing.cpp:44-71) and the closest-hit update.  Smaller t wins;
-// equal t keeps the lower sphere index whatever order groups are resolved in.
-RT_DEV void resolve_group(const float4* __restrict__ tab, uint32_t g, V3 o, V3 d, float a, float& tmin, int& idx) {
+// equal t keeps the lower ORIGINAL sphere index whatever order groups are stored or resolved in.
+RT_DEV void resolve_group(const float4* __restrict__ tab, const uint32_t* __restrict__ orig, uint32_t g, V3 o, V3 d, float a, float& tmin,
+                          int& idx) {
     const float4 S0 = tab[g], S1 = tab[g + 1], S2 = tab[g + 2], S3 = tab[g + 3];
     float b0, b1, b2, b3, e0, e1, e2, e3;
 #define RT_DISC(S, B, E)                                               \
@@ -257,7 +241,7 @@ RT_DEV void resolve_group(const float4* __restrict__ tab, uint32_t g, V3 o, V3 d
         float t = (-b - sq) / a;               // ray-tracing.cpp:56
         if (!(t > 0.001f)) t = (-b + sq) / a;  // :69
         const int cand = (int)(g + k);
-        if (t > 0.001f && (t < tmin || (t == tmin && cand < idx))) {
+        if (t > 0.001f && (t < tmin || (t == tmin && idx >= 0 && orig[cand] < orig[idx]))) {
             tmin = t;
             idx = cand;
         }
@@ -265,7 +249,8 @@ RT_DEV void resolve_group(const float4* __restrict__ tab, uint32_t g, V3 o, V3 d
 }
 
 // cand: this lane's column of the wave's candidate list in LDS; slot stride is 64 entries.
-RT_DEV void scan_list_deferred(const float4* __restrict__ tab, uint32_t nPadded, V3 o, V3 d, float& tmin, int& idx, uint16_t* cand) {
+RT_DEV void scan_list_deferred(const float4* __restrict__ tab, const uint32_t* __restrict__ orig, uint32_t nPadded, V3 o, V3 d, float& tmin,
+                               int& idx, uint16_t* cand) {
     const float a = dot3(d, d);
     tmin = __builtin_inff();
     idx = -1;
@@ -292,7 +277,7 @@ RT_DEV void scan_list_deferred(const float4* __restrict__ tab, uint32_t nPadded,
         for (uint32_t it = 0; __ballot(it < cnt) != 0ull; ++it) {
             if (it < cnt) {
                 const uint32_t g = cand[it * kWaveSize];
-                resolve_group(tab, g, o, d, a, tmin, idx);
+                resolve_group(tab, orig, g, o, d, a, tmin, idx);
             }
         }
         cnt = 0;
@@ -301,67 +286,69 @@ RT_DEV void scan_list_deferred(const float4* __restrict__ tab, uint32_t nPadded,
 }
 
 // ------------------------------------------------ list scan with a matrix-core pre-filter
-// The all-pairs test "which of these 64 rays can hit which of these N spheres" IS a dense
-// contraction: b = d.(o - c) = [d, d.o].[-c, 1] and a*cc = a|o|^2 + [-2a o, a].[c, |c|^2 - r^2] are
-// K = 4 inner products between a per-ray and a per-sphere vector.  gfx950's v_mfma_f32_32x32x2_f32
-// computes them as exact f32 FMA chains at 64 flop/clk/SIMD on the matrix pipe, which runs beside the
-// VALU — against 17 VALU instructions per sphere for the reference-order arithmetic.  The MFMA
-// result is NOT the reference's rounding, so it is used only as a conservative FILTER:
-//     F = b~^2 - a*cc~ + M,   M = K eps a (2|o|^2 + 2|c|^2 + r^2),  K = 64, eps = 2^-24
-// M exceeds the sum of the rounding-error bounds of the reference-order discriminant and of the
-// filter (<= 46 eps a ((|o|+|c|)^2 + r^2)), so disc_ref > 0 implies F > 0: no sphere
-// the reference would hit is ever dropped.  Groups with a non-negative F are recorded per ray and then
-// resolved EXACTLY by resolve_group (reference-order VALU arithmetic), so the image is bit-identical
-// to the pure-VALU scan and to the oracle; the filter only decides how much exact work is skipped.
+// "Which of these 64 rays can hit which of these groups" is a dense contraction: for a bounding sphere
+// (C, R) and a ray (o, d), b = d.(o - C) = [d, d.o].[-C, 1] and a*cc = a|o|^2 + [-2a o, a].[C, |C|^2 - R^2]
+// are K = 4 inner products of a per-ray with a per-group vector.  v_mfma_f32_32x32x2_f32 evaluates
+// 32 groups x 32 rays per instruction as exact f32 FMA chains.  That is NOT the reference's rounding, so
+// it is used only as a conservative FILTER over the group bounds:
+//     F = b~^2 - a*cc~ + M >= 0   =>   the group is recorded for that ray
+// and every recorded group is then resolved EXACTLY by resolve_group (reference-order VALU arithmetic on
+// the four member spheres).  The image is bit-identical to an exhaustive scan: the filter only decides
+// how much exact work is skipped.  Conservativeness (DESIGN.md §5.1 has the derivation): if the
+// reference-order discriminant of a member sphere i is positive, the ray's line passes within
+// sqrt(r_i^2 + E_i/a) of c_i, hence within s_i + that of C; with R >= s_i + r_i the true bound
+// discriminant exceeds -(E_i + 2 s_i sqrt(a E_i)) >= -(101 E_i + 0.01 a s_i^2).  The host folds 0.01 s_max^2
+// and K eps (2(|C|+R)^2 + R^2) into Rf^2 and the kernel adds 2 K eps a|o|^2 per ray, K = 2048 > 101*16 + 30
+// (E_i <= 16 eps a G and the filter's own rounding <= 30 eps a G, G = 2|o|^2 + 2(|C|+R)^2 + R^2).
 //
-// Tile mapping (32 spheres x 32 rays per MFMA, spheres = rows/A, rays = columns/B): lane l supplies
-// A[l&31][l>>5] and B[l>>5][l&31]; it receives, for ray column l&31, the 16 sphere rows
-// (r&3) + 8(r>>2) + 4(l>>5) — i.e. registers 4g..4g+3 are one aligned group of four consecutive
-// spheres.  Rays 0-31 and 32-63 are two column tiles; lane l and lane l^32 split each ray's spheres,
-// so every ray has two producer lanes, each with its own sub-list and register counter (no atomics).
+// Tile mapping (groups = rows/A, rays = columns/B): lane l supplies A[l&31][l>>5] and B[l>>5][l&31] and
+// receives, for ray column l&31, the 16 group rows (r&3) + 8(r>>2) + 4(l>>5).  Rays 0-31 and 32-63 are two
+// column tiles; lanes l and l^32 split each ray's groups, so every ray has two producer lanes, each
+// with its own sub-list and register counter (no atomics).  A sub-list that overflows makes its ray
+// fall back to resolving every group (rare; still exact).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr uint32_t kMfmaSlots = 12;                                    // entries per (ray, half) sub-list
-constexpr uint32_t kWaveCandBytes = 64 * 2 * kMfmaSlots * 2 + 128 * 2;  // lists + counts = 3328 B per wave
-constexpr float kMarginRel = 64.f * 5.9604645e-8f;                     // K * eps
+constexpr uint32_t kMfmaSlots = 14;                                    // entries per (ray, half) sub-list
+constexpr uint32_t kWaveCandBytes = 64 * 2 * kMfmaSlots * 2 + 128 * 2;  // lists + counts = 3840 B per wave
+constexpr float kMarginRel = 2048.f * 5.9604645e-8f;                   // K * eps, K = 2048 (host uses the same K)
 
-// Sphere operand image for the filter, built once per workgroup: ops[tile][4][64] floats.
-RT_DEV void build_mfma_operands(const float4* __restrict__ scan, uint32_t nReal, uint32_t nTiles, float* __restrict__ ops, uint32_t tid,
+// Group operand image for the filter, built once per workgroup: ops[tile][4][64] floats.
+RT_DEV void build_mfma_operands(const float4* __restrict__ bounds, uint32_t nGroups, uint32_t nTiles, float* __restrict__ ops, uint32_t tid,
                                 uint32_t nthreads) {
     for (uint32_t e = tid; e < nTiles * 64; e += nthreads) {
         const uint32_t t = e >> 6, l = e & 63, h = l >> 5;
-        const uint32_t si = t * 32 + (l & 31);
-        float4 S = make_float4(0.f, 0.f, 0.f, -1.f);
-        if (si < nReal) S = scan[si];
-        float w = 1e30f;  // padding rows: a*cc~ = +huge => F < 0, never recorded
-        if (S.w >= 0.f) {
-            const float c2 = (S.x * S.x + S.y * S.y) + S.z * S.z;
-            w = (c2 - S.w) - kMarginRel * (2.f * c2 + S.w);
-        }
+        const uint32_t gi = t * 32 + (l & 31);
+        float4 B = make_float4(0.f, 0.f, 0.f, 1e30f);  // padding rows: a*cc~ = +huge => F < 0, never recorded
+        if (gi < nGroups) B = bounds[gi];
         float* o = ops + (size_t)t * 256 + l;
-        o[0] = h == 0 ? -S.x : -S.y;
-        o[64] = h == 0 ? -S.z : 1.f;
-        o[128] = h == 0 ? S.x : S.y;
-        o[192] = h == 0 ? S.z : w;
+        o[0] = h == 0 ? -B.x : -B.y;
+        o[64] = h == 0 ? -B.z : 1.f;
+        o[128] = h == 0 ? B.x : B.y;
+        o[192] = h == 0 ? B.z : B.w;
     }
 }
 
-RT_DEV void mfma_post(const f32x16& Tb, const f32x16& Tg, float cray, uint16_t* list, uint32_t& cnt, uint32_t base) {
+// Record the groups of this lane's 16 rows whose filter value is non-negative.
+RT_DEV void mfma_post(const f32x16& Tb, const f32x16& Tg, float cray, uint16_t* list, uint32_t& cnt, uint32_t rowBase) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const float f0 = __builtin_fmaf(Tb[4 * g + 0], Tb[4 * g + 0], -(Tg[4 * g + 0] + cray));
-        const float f1 = __builtin_fmaf(Tb[4 * g + 1], Tb[4 * g + 1], -(Tg[4 * g + 1] + cray));
-        const float f2 = __builtin_fmaf(Tb[4 * g + 2], Tb[4 * g + 2], -(Tg[4 * g + 2] + cray));
-        const float f3 = __builtin_fmaf(Tb[4 * g + 3], Tb[4 * g + 3], -(Tg[4 * g + 3] + cray));
-        const int signs = __float_as_int(f0) & __float_as_int(f1) & __float_as_int(f2) & __float_as_int(f3);
+        float f[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = __builtin_fmaf(Tb[4 * g + q], Tb[4 * g + q], -(Tg[4 * g + q] + cray));
+        const int signs = __float_as_int(f[0]) & __float_as_int(f[1]) & __float_as_int(f[2]) & __float_as_int(f[3]);
         if (__builtin_expect(signs >= 0, 0)) {
-            list[cnt] = (uint16_t)(base + 8u * (uint32_t)g);
-            ++cnt;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (__float_as_int(f[q]) >= 0) {
+                    if (cnt < kMfmaSlots) list[cnt] = (uint16_t)(rowBase + 8u * (uint32_t)g + (uint32_t)q);
+                    ++cnt;  // keeps counting past the capacity: the owner then resolves every group
+                }
+            }
         }
     }
 }
 
-RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float* __restrict__ ops, uint32_t nTiles, V3 o, V3 d, bool live, float& tmin,
-                           int& idx, uint16_t* waveCand, uint32_t lane) {
+RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __restrict__ orig, const float* __restrict__ ops, uint32_t nTiles,
+                           uint32_t nGroups, V3 o, V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand, uint32_t lane) {
     const float a = dot3(d, d);
     tmin = __builtin_inff();
     idx = -1;
@@ -378,8 +365,8 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float* __restri
     const float pcr = __shfl_xor(cr, 32);
     const bool lo = half == 0u;
     // B operands: tile 0 = rays 0..31 (owner lanes 0..31), tile 1 = rays 32..63 (owner lanes 32..63)
-    const float bb00 = lo ? d.x : pdy, bb01 = lo ? d.z : pdO;   // tile 0: k = 0,2 from the owner, k = 1,3 from lane-32
-    const float bb10 = lo ? pdx : d.y, bb11 = lo ? pdz : dO;    // tile 1
+    const float bb00 = lo ? d.x : pdy, bb01 = lo ? d.z : pdO;  // tile 0: k = 0,2 from the owner, k = 1,3 from lane-32
+    const float bb10 = lo ? pdx : d.y, bb11 = lo ? pdz : dO;   // tile 1
     const float bg00 = lo ? gx : pgy, bg01 = lo ? gz : pa;
     const float bg10 = lo ? pgx : gy, bg11 = lo ? pgz : a;
     const float cr0 = lo ? cr : pcr, cr1 = lo ? pcr : cr;
@@ -388,41 +375,38 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float* __restri
     uint16_t* list0 = lists + ((col * 2u + half) * kMfmaSlots);
     uint16_t* list1 = lists + (((col + 32u) * 2u + half) * kMfmaSlots);
     uint32_t cnt0 = 0, cnt1 = 0;
-    uint32_t s = 0;
-    for (;;) {
-        bool nearlyFull = false;
-        for (; s < nTiles && !nearlyFull; ++s) {
-            const float* op = ops + (size_t)s * 256 + lane;
-            const float ab1 = op[0], ab2 = op[64], ag1 = op[128], ag2 = op[192];
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            f32x16 Tb0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab1, bb00, zero, 0, 0, 0);
-            f32x16 Tg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag1, bg00, zero, 0, 0, 0);
-            f32x16 Tb1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab1, bb10, zero, 0, 0, 0);
-            f32x16 Tg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag1, bg10, zero, 0, 0, 0);
-            Tb0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab2, bb01, Tb0, 0, 0, 0);
-            Tg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag2, bg01, Tg0, 0, 0, 0);
-            Tb1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab2, bb11, Tb1, 0, 0, 0);
-            Tg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag2, bg11, Tg1, 0, 0, 0);
-            const uint32_t base = 32u * s + 4u * half;
-            mfma_post(Tb0, Tg0, cr0, list0, cnt0, base);
-            mfma_post(Tb1, Tg1, cr1, list1, cnt1, base);
-            nearlyFull = __ballot((cnt0 > cnt1 ? cnt0 : cnt1) + 4u > kMfmaSlots) != 0ull;
+    for (uint32_t s = 0; s < nTiles; ++s) {
+        const float* op = ops + (size_t)s * 256 + lane;
+        const float ab1 = op[0], ab2 = op[64], ag1 = op[128], ag2 = op[192];
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 Tb0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab1, bb00, zero, 0, 0, 0);
+        f32x16 Tg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag1, bg00, zero, 0, 0, 0);
+        f32x16 Tb1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab1, bb10, zero, 0, 0, 0);
+        f32x16 Tg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag1, bg10, zero, 0, 0, 0);
+        Tb0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab2, bb01, Tb0, 0, 0, 0);
+        Tg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag2, bg01, Tg0, 0, 0, 0);
+        Tb1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab2, bb11, Tb1, 0, 0, 0);
+        Tg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag2, bg11, Tg1, 0, 0, 0);
+        const uint32_t rowBase = 32u * s + 4u * half;
+        mfma_post(Tb0, Tg0, cr0, list0, cnt0, rowBase);
+        mfma_post(Tb1, Tg1, cr1, list1, cnt1, rowBase);
+    }
+    // publish the producers' counts, then every lane resolves its OWN ray's two sub-lists
+    counts[col * 2u + half] = (uint16_t)(cnt0 < 0xffffu ? cnt0 : 0xffffu);
+    counts[(col + 32u) * 2u + half] = (uint16_t)(cnt1 < 0xffffu ? cnt1 : 0xffffu);
+    uint32_t c0 = counts[lane * 2u], c1 = counts[lane * 2u + 1u];
+    const bool overflow = c0 > kMfmaSlots || c1 > kMfmaSlots;
+    if (overflow) {  // exhaustive (still exact) fallback for this ray
+        c0 = nGroups;
+        c1 = 0;
+    }
+    const uint32_t tot = c0 + c1;
+    const uint16_t* mine = lists + lane * 2u * kMfmaSlots;
+    for (uint32_t it = 0; __ballot(it < tot) != 0ull; ++it) {
+        if (it < tot) {
+            const uint32_t gid = overflow ? it : (it < c0 ? mine[it] : mine[kMfmaSlots + (it - c0)]);
+            resolve_group(tab, orig, 4u * gid, o, d, a, tmin, idx);
         }
-        // publish the producers' counts, then every lane resolves its OWN ray's two sub-lists
-        counts[col * 2u + half] = (uint16_t)cnt0;
-        counts[(col + 32u) * 2u + half] = (uint16_t)cnt1;
-        const uint32_t c0 = counts[lane * 2u], c1 = counts[lane * 2u + 1u];
-        const uint32_t tot = c0 + c1;
-        const uint16_t* mine = lists + lane * 2u * kMfmaSlots;
-        for (uint32_t it = 0; __ballot(it < tot) != 0ull; ++it) {
-            if (it < tot) {
-                const uint32_t g = it < c0 ? mine[it] : mine[kMfmaSlots + (it - c0)];
-                resolve_group(tab, g, o, d, a, tmin, idx);
-            }
-        }
-        cnt0 = 0;
-        cnt1 = 0;
-        if (s >= nTiles) break;
     }
 }
 
@@ -587,30 +571,35 @@ template <bool kLds, int kThreads, bool kMfma>
 __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p) {
     extern __shared__ float4 smem[];
     const float4* scanTab = p.scan;
+    const uint32_t* origTab = p.orig;
     const float* radTab = p.radius;
     const rt_material* matTab = p.mats;
     // per-wave candidate regions first (kWaveCandBytes each; the VALU scan uses the first 2 KiB of its region)
     uint16_t* candBase = reinterpret_cast<uint16_t*>(smem);
     float4* tabBase = smem + (kThreads / kWaveSize) * (kWaveCandBytes / 16);
     const float* mfmaOps = nullptr;
-    const uint32_t nTiles = (p.n + 31u) / 32u;
+    const uint32_t nTiles = (p.n_groups + 31u) / 32u;
     if (kLds) {
-        // LDS image: [n_padded] float4 scan | [n] rt_material (48 B = 3 float4) | [n] float radius
+        // LDS image (16-byte aligned pieces): scan | orig | materials (48 B = 3 float4) | radii | filter operands
         float4* ldsScan = tabBase;
-        float4* ldsMat = tabBase + p.n_padded;
-        float* ldsRad = reinterpret_cast<float*>(tabBase + (size_t)p.n_padded + (size_t)p.n * 3);
+        uint32_t* ldsOrig = reinterpret_cast<uint32_t*>(ldsScan + p.n_padded);
+        float4* ldsMat = reinterpret_cast<float4*>(ldsOrig + p.n_padded);  // n_padded is a multiple of 4
+        float* ldsRad = reinterpret_cast<float*>(ldsMat + (size_t)p.n * 3);
         const float4* gMat = reinterpret_cast<const float4*>(p.mats);
-        for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) ldsScan[k] = p.scan[k];
+        for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) {
+            ldsScan[k] = p.scan[k];
+            ldsOrig[k] = p.orig[k];
+        }
         for (uint32_t k = threadIdx.x; k < p.n * 3; k += blockDim.x) ldsMat[k] = gMat[k];
         for (uint32_t k = threadIdx.x; k < p.n; k += blockDim.x) ldsRad[k] = p.radius[k];
         if (kMfma) {
-            // filter operand image after the radii (16-byte aligned): nTiles x 4 x 64 floats
-            float* ldsOps = reinterpret_cast<float*>(tabBase + (size_t)p.n_padded + (size_t)p.n * 3 + (p.n + 3u) / 4u);
-            build_mfma_operands(p.scan, p.n, nTiles, ldsOps, threadIdx.x, blockDim.x);
+            float* ldsOps = ldsRad + ((p.n + 3u) & ~3u);
+            build_mfma_operands(p.bounds, p.n_groups, nTiles, ldsOps, threadIdx.x, blockDim.x);
             mfmaOps = ldsOps;
         }
         __syncthreads();
         scanTab = ldsScan;
+        origTab = ldsOrig;
         radTab = ldsRad;
         matTab = reinterpret_cast<const rt_material*>(ldsMat);
     }
@@ -684,9 +673,9 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
         if (kMfma) {
             // every lane takes part: lane l also supplies operands for, and filters half the spheres of,
             // the ray owned by lane l^32, whether or not its own ray is live
-            scan_list_mfma(scanTab, mfmaOps, nTiles, ro, rd, state != kIdle, tmin, idx, waveCand, lane);
+            scan_list_mfma(scanTab, origTab, mfmaOps, nTiles, p.n_groups, ro, rd, state != kIdle, tmin, idx, waveCand, lane);
         } else if (state != kIdle) {
-            scan_list_deferred(scanTab, p.n_padded, ro, rd, tmin, idx, cand);
+            scan_list_deferred(scanTab, origTab, p.n_padded, ro, rd, tmin, idx, cand);
         }
         if (state != kIdle) {
             ++nTrav;
@@ -704,8 +693,9 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
                 finished = true;
             } else {
                 const float4 S = scanTab[idx];
-                const float radius = radTab[idx];
-                const Mat m = load_material(matTab, idx);
+                const uint32_t oi = origTab[idx];  // original list index: material i belongs to sphere i
+                const float radius = radTab[oi];
+                const Mat m = load_material(matTab, (int)oi);
                 const V3 center = v3(S.x, S.y, S.z);
                 const V3 pos = tmin * rd + ro;          // XMVectorMultiplyAdd(t, dir, origin), ray-tracing.cpp:57
                 const V3 nrm = (pos - center) / radius;  // ray-tracing.cpp:58
@@ -839,14 +829,15 @@ __global__ void k_unit_closest(const TraceParams p, const float* rays, uint32_t 
     const V3 o = v3(r[0], r[1], r[2]), d = v3(r[3], r[4], r[5]);
     float tmin;
     int idx;
-    scan_list(p.scan, p.n_padded, o, d, tmin, idx);
+    scan_list(p.scan, p.orig, p.n_padded - 4u, o, d, tmin, idx);
     float* w = out + 10 * (size_t)k;
     for (int c = 0; c < 10; ++c) w[c] = 0.f;
-    w[1] = __int_as_float(idx);
+    const int oidx = idx >= 0 ? (int)p.orig[idx] : -1;
+    w[1] = __int_as_float(oidx);
     if (idx >= 0) {
         const float4 S = p.scan[idx];
         const V3 pos = tmin * d + o;
-        const V3 nrm = (pos - v3(S.x, S.y, S.z)) / p.radius[idx];
+        const V3 nrm = (pos - v3(S.x, S.y, S.z)) / p.radius[oidx];
         w[0] = tmin;
         w[2] = pos.x; w[3] = pos.y; w[4] = pos.z;
         w[5] = nrm.x; w[6] = nrm.y; w[7] = nrm.z;
