@@ -118,6 +118,7 @@ struct SceneLayout {
     std::vector<uint32_t> orig;   // same length
     std::vector<float4> bounds;   // nGroups
     uint32_t nGroups = 0;
+    float boundNorm = 0.f;        // max |C| + R
 };
 
 static void BuildLayout(const rt_sphere* sp, uint32_t n, SceneLayout& L) {
@@ -198,6 +199,7 @@ static void BuildLayout(const rt_sphere* sp, uint32_t n, SceneLayout& L) {
         float w = (float)(C2 - Rf2);
         w = std::nextafterf(std::nextafterf(w, -INFINITY), -INFINITY);  // err towards "more candidates"
         L.bounds[gi] = make_float4(Cf[0], Cf[1], Cf[2], w);
+        L.boundNorm = std::max(L.boundNorm, (float)((Cn + R) * 1.001));
     }
 }
 static size_t LdsBytesFor(uint32_t n, uint32_t nPadded) { return (size_t)nPadded * (16 + 4) + (size_t)n * 48 + (size_t)((n + 3) / 4) * 16; }
@@ -286,14 +288,16 @@ int rt_create(int device_ordinal, rt_ctx** out) {
     RT_HIP(hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking));
     ctx->stream = ctx->ownStream;
     for (auto& ev : ctx->ev) RT_HIP(hipEventCreate(&ev));
-    ctx->blocksPerCu = EnvU32("RT_BLOCKS_PER_CU", 4);
-    if (ctx->blocksPerCu == 0) ctx->blocksPerCu = 1;
-    ctx->forceGlobal = EnvU32("RT_FORCE_GLOBAL_TABLES", 0) != 0;
     {
         const char* scan = std::getenv("RT_SCAN");
         ctx->useMfma = !(scan && std::strcmp(scan, "valu") == 0);
     }
-    ctx->blockThreads = EnvU32("RT_BLOCK_THREADS", 256);
+    // launch geometry (sweeps: profiles/r01_sweep_*.jsonl): the matrix-core scan wants 16 waves per CU in ONE
+    // 1024-thread workgroup (one LDS image, 128 VGPRs); the pure-VALU scan runs 4 x 256 threads
+    ctx->blocksPerCu = EnvU32("RT_BLOCKS_PER_CU", ctx->useMfma ? 1 : 4);
+    if (ctx->blocksPerCu == 0) ctx->blocksPerCu = 1;
+    ctx->forceGlobal = EnvU32("RT_FORCE_GLOBAL_TABLES", 0) != 0;
+    ctx->blockThreads = EnvU32("RT_BLOCK_THREADS", ctx->useMfma ? 1024 : 256);
     if (ctx->blockThreads != 256 && ctx->blockThreads != 384 && ctx->blockThreads != 512 && ctx->blockThreads != 768 &&
         ctx->blockThreads != 1024)
         ctx->blockThreads = 256;
@@ -371,6 +375,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     b.orig = ctx->orig.ptr;
     b.bounds = ctx->bounds.ptr;
     b.n_groups = L.nGroups;
+    b.bound_norm = L.boundNorm;
     b.radius = ctx->radius.ptr;
     b.mats = ctx->mats.ptr;
     b.n = n;
@@ -730,5 +735,32 @@ int rt_unit_tonemap(rt_ctx* ctx, const float* hdr_rgb, uint32_t n, uint32_t n_sa
     RT_HIP(hipMemcpy(out_rgb, dOut.p, (size_t)n * 3, hipMemcpyDeviceToHost));
     return RT_OK;
 }
+
+// Host-only: the clustered layout rt_scene_upload builds (no device needed).  orig: 4 entries per group
+// (0xffffffff = padding), bounds: Cx, Cy, Cz, |C|^2 - Rf^2 per group.  Pass cap_groups = 0 to query the count.
+int rt_unit_layout(const rt_sphere* spheres, uint32_t n, uint32_t cap_groups, uint32_t* n_groups, uint32_t* orig, float* bounds) {
+    if (!spheres || n == 0 || !n_groups) return Fail(RT_ERR_INVALID_ARG, "rt_unit_layout: invalid argument");
+    SceneLayout L;
+    BuildLayout(spheres, n, L);
+    *n_groups = L.nGroups;
+    if (cap_groups == 0) return RT_OK;
+    if (cap_groups < L.nGroups || !orig || !bounds) return Fail(RT_ERR_INVALID_ARG, "rt_unit_layout: capacity too small");
+    std::memcpy(orig, L.orig.data(), (size_t)L.nGroups * 4 * sizeof(uint32_t));
+    std::memcpy(bounds, L.bounds.data(), (size_t)L.nGroups * sizeof(float4));
+    return RT_OK;
+}
+
+#ifdef RT_STAMPS
+// Diagnostic build only: read and clear the section clocks (see rt_kernels.h g_dbg).
+int rt_debug_stamps(rt_ctx* ctx, unsigned long long out[8]) {
+    if (!ctx || !out) return Fail(RT_ERR_INVALID_ARG, "rt_debug_stamps: invalid argument");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(rtd::g_dbg), 8 * sizeof(unsigned long long)));
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    RT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_dbg), z, sizeof(z)));
+    return RT_OK;
+}
+#endif
 
 }  // extern "C"

@@ -35,6 +35,24 @@
 
 namespace rtd {
 
+// Diagnostic build only (-DRT_STAMPS): per-section shader-clock sums go to g_dbg[], which no kernel reads.
+// The shipped library is built without it.
+#ifdef RT_STAMPS
+static __device__ unsigned long long g_dbg[8];  // refill, scan, transitions, iterations, filter, resolve, resolve items, -
+RT_DEV unsigned long long rt_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define RT_STAMP(var) const unsigned long long var = rt_stamp()
+#define RT_ACC(sum, a, b) sum += (b) - (a)
+#else
+#define RT_STAMP(var)
+#define RT_ACC(sum, a, b)
+#endif
+
 constexpr int kWaveSize = 64;
 constexpr uint32_t kQueueBlock = 256;  // paths a wave takes from the global queue per atomic
 
@@ -50,6 +68,7 @@ struct TraceParams {
     const rt_material* mats;   // [n] by original index
     uint32_t n;                // real spheres
     uint32_t n_groups;         // groups of four entries (even)
+    float bound_norm;          // max over groups of |C| + R (scale of the filter's behind-the-origin threshold)
     uint32_t n_padded;         // 4 * n_groups + 4
     float cam_o[3], cam_x[3], cam_y[3], cam_oip[3];
     float aperture, focal;
@@ -327,18 +346,29 @@ RT_DEV void build_mfma_operands(const float4* __restrict__ bounds, uint32_t nGro
     }
 }
 
-// Record the groups of this lane's 16 rows whose filter value is non-negative.
-RT_DEV void mfma_post(const f32x16& Tb, const f32x16& Tg, float cray, uint16_t* list, uint32_t& cnt, uint32_t rowBase) {
+// Record the groups of this lane's 16 rows that the ray may hit: filter value F = b~^2 - t >= 0 (t = a*cc~ - M)
+// and NOT surely behind the origin.  "Behind" = the origin is outside the inflated bound (t > 0, which already
+// includes the margin) and the centre is behind it by more than the rounding of b~ (b~ > bthr, bthr =
+// 1e-4 sqrt(a) (|o| + max(|C|+R)) >= 185x the error bound 9 eps sqrt(a)(|o|+|C|)): then every point of the bound,
+// hence of its member spheres, has t < 0 and the reference accepts no root (bias 0.001, ray-tracing.cpp:52).
+// All three conditions are sign bits; one 3-input bit operation per element forms "rejected".
+RT_DEV void mfma_post(const f32x16& Tb, const f32x16& Tg, float cray, float bthr, uint16_t* list, uint32_t& cnt, uint32_t rowBase) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        float f[4];
+        int rej[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) f[q] = __builtin_fmaf(Tb[4 * g + q], Tb[4 * g + q], -(Tg[4 * g + q] + cray));
-        const int signs = __float_as_int(f[0]) & __float_as_int(f[1]) & __float_as_int(f[2]) & __float_as_int(f[3]);
-        if (__builtin_expect(signs >= 0, 0)) {
+        for (int q = 0; q < 4; ++q) {
+            const float t = Tg[4 * g + q] + cray;
+            const float f = __builtin_fmaf(Tb[4 * g + q], Tb[4 * g + q], -t);
+            const float u = bthr - Tb[4 * g + q];  // negative <=> centre behind the origin
+            // rejected = sign(f) | (sign(u) & ~sign(t))
+            rej[q] = __float_as_int(f) | (__float_as_int(u) & ~__float_as_int(t));
+        }
+        const int all = rej[0] & rej[1] & rej[2] & rej[3];
+        if (__builtin_expect(all >= 0, 0)) {  // some element has a clear sign bit: a candidate
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (__float_as_int(f[q]) >= 0) {
+                if (rej[q] >= 0) {
                     if (cnt < kMfmaSlots) list[cnt] = (uint16_t)(rowBase + 8u * (uint32_t)g + (uint32_t)q);
                     ++cnt;  // keeps counting past the capacity: the owner then resolves every group
                 }
@@ -348,7 +378,8 @@ RT_DEV void mfma_post(const f32x16& Tb, const f32x16& Tg, float cray, uint16_t* 
 }
 
 RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __restrict__ orig, const float* __restrict__ ops, uint32_t nTiles,
-                           uint32_t nGroups, V3 o, V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand, uint32_t lane) {
+                           uint32_t nGroups, float boundNorm, V3 o, V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand,
+                           uint32_t lane, unsigned long long* dbg) {
     const float a = dot3(d, d);
     tmin = __builtin_inff();
     idx = -1;
@@ -358,11 +389,13 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __res
     const float m2a = -2.f * a;
     const float gx = m2a * o.x, gy = m2a * o.y, gz = m2a * o.z;
     // a dead ray's a*cc~ is made huge so that nothing is ever recorded for it
-    const float cr = live ? (a * dot3(o, o)) * (1.f - 2.f * kMarginRel) : 1e30f;
+    const float oo = dot3(o, o);
+    const float cr = live ? (a * oo) * (1.f - 2.f * kMarginRel) : 1e30f;
+    const float bt = 1e-4f * __builtin_sqrtf(a) * (__builtin_sqrtf(oo) + boundNorm);
     // the other half-wave's ray (lane ^ 32)
     const float pdx = __shfl_xor(d.x, 32), pdy = __shfl_xor(d.y, 32), pdz = __shfl_xor(d.z, 32), pdO = __shfl_xor(dO, 32);
     const float pgx = __shfl_xor(gx, 32), pgy = __shfl_xor(gy, 32), pgz = __shfl_xor(gz, 32), pa = __shfl_xor(a, 32);
-    const float pcr = __shfl_xor(cr, 32);
+    const float pcr = __shfl_xor(cr, 32), pbt = __shfl_xor(bt, 32);
     const bool lo = half == 0u;
     // B operands: tile 0 = rays 0..31 (owner lanes 0..31), tile 1 = rays 32..63 (owner lanes 32..63)
     const float bb00 = lo ? d.x : pdy, bb01 = lo ? d.z : pdO;  // tile 0: k = 0,2 from the owner, k = 1,3 from lane-32
@@ -370,11 +403,13 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __res
     const float bg00 = lo ? gx : pgy, bg01 = lo ? gz : pa;
     const float bg10 = lo ? pgx : gy, bg11 = lo ? pgz : a;
     const float cr0 = lo ? cr : pcr, cr1 = lo ? pcr : cr;
+    const float bt0 = lo ? bt : pbt, bt1 = lo ? pbt : bt;
     uint16_t* lists = waveCand;
     uint16_t* counts = waveCand + 64 * 2 * kMfmaSlots;
     uint16_t* list0 = lists + ((col * 2u + half) * kMfmaSlots);
     uint16_t* list1 = lists + (((col + 32u) * 2u + half) * kMfmaSlots);
     uint32_t cnt0 = 0, cnt1 = 0;
+    RT_STAMP(tf0);
     for (uint32_t s = 0; s < nTiles; ++s) {
         const float* op = ops + (size_t)s * 256 + lane;
         const float ab1 = op[0], ab2 = op[64], ag1 = op[128], ag2 = op[192];
@@ -388,9 +423,10 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __res
         Tb1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab2, bb11, Tb1, 0, 0, 0);
         Tg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag2, bg11, Tg1, 0, 0, 0);
         const uint32_t rowBase = 32u * s + 4u * half;
-        mfma_post(Tb0, Tg0, cr0, list0, cnt0, rowBase);
-        mfma_post(Tb1, Tg1, cr1, list1, cnt1, rowBase);
+        mfma_post(Tb0, Tg0, cr0, bt0, list0, cnt0, rowBase);
+        mfma_post(Tb1, Tg1, cr1, bt1, list1, cnt1, rowBase);
     }
+    RT_STAMP(tf1);
     // publish the producers' counts, then every lane resolves its OWN ray's two sub-lists
     counts[col * 2u + half] = (uint16_t)(cnt0 < 0xffffu ? cnt0 : 0xffffu);
     counts[(col + 32u) * 2u + half] = (uint16_t)(cnt1 < 0xffffu ? cnt1 : 0xffffu);
@@ -408,6 +444,17 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __res
             resolve_group(tab, orig, 4u * gid, o, d, a, tmin, idx);
         }
     }
+#ifdef RT_STAMPS
+    {
+        RT_STAMP(tf2);
+        dbg[0] += tf1 - tf0;
+        dbg[1] += tf2 - tf1;
+        dbg[2] += tot;
+        uint32_t mx = tot;
+        for (int off = 32; off > 0; off >>= 1) { const uint32_t o2 = __shfl_xor(mx, off); mx = o2 > mx ? o2 : mx; }
+        dbg[3] += mx;
+    }
+#endif
 }
 
 // --------------------------------------------------------- textures (A14), getters (A13)
@@ -561,6 +608,8 @@ RT_DEV uint32_t prefix_count(uint64_t mask) {
 
 enum : uint32_t { kIdle = 0u, kNeedClosest = 1u, kNeedShadow = 2u };
 
+
+
 // ============================================================================ megakernel
 // Persistent threads: every wave loops { refill idle lanes from the queue; one list scan for all
 // lanes; per-lane state transition } until the queue is empty and all its lanes are idle.  Waves
@@ -622,7 +671,13 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
     uint32_t blkNext = 0, blkEnd = 0;
     bool queueEmpty = false;
 
+    unsigned long long dbgScan[4] = {0, 0, 0, 0};
+    (void)dbgScan;
+#ifdef RT_STAMPS
+    unsigned long long cyRefill = 0, cyScan = 0, cyTrans = 0, cyIters = 0;
+#endif
     for (;;) {
+        RT_STAMP(ts0);
         // ------------------------------------------------ refill idle lanes (ballot + prefix)
         uint64_t idleMask = __ballot(state == kIdle);
         while (idleMask != 0ull && !queueEmpty) {
@@ -667,13 +722,14 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
         }
         if (__ballot(state != kIdle) == 0ull) break;  // queue empty and every lane drained
 
+        RT_STAMP(ts1);
         // ------------------------------------------------ one list scan for every live lane
         float tmin = 0.f;
         int idx = -1;
         if (kMfma) {
             // every lane takes part: lane l also supplies operands for, and filters half the spheres of,
             // the ray owned by lane l^32, whether or not its own ray is live
-            scan_list_mfma(scanTab, origTab, mfmaOps, nTiles, p.n_groups, ro, rd, state != kIdle, tmin, idx, waveCand, lane);
+            scan_list_mfma(scanTab, origTab, mfmaOps, nTiles, p.n_groups, p.bound_norm, ro, rd, state != kIdle, tmin, idx, waveCand, lane, dbgScan);
         } else if (state != kIdle) {
             scan_list_deferred(scanTab, origTab, p.n_padded, ro, rd, tmin, idx, cand);
         }
@@ -682,6 +738,7 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
             ++pathTrav;
         }
 
+        RT_STAMP(ts2);
         // ------------------------------------------------ state transitions
         bool finished = false;
         if (state == kNeedClosest) {
@@ -724,6 +781,13 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
             if (p.trav_out) p.trav_out[q] = pathTrav;
             state = kIdle;
         }
+        RT_STAMP(ts3);
+        RT_ACC(cyRefill, ts0, ts1);
+        RT_ACC(cyScan, ts1, ts2);
+        RT_ACC(cyTrans, ts2, ts3);
+#ifdef RT_STAMPS
+        cyIters += 1;
+#endif
     }
 
     // counters: wave reduce, one atomic pair per wave
@@ -732,9 +796,25 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
         t += __shfl_down(t, off);
         s += __shfl_down(s, off);
     }
+#ifdef RT_STAMPS
+    {
+        unsigned long long it = dbgScan[2];
+        for (int off = 32; off > 0; off >>= 1) it += __shfl_down(it, off);
+        if (lane == 0) atomicAdd(&g_dbg[6], it);
+    }
+#endif
     if (lane == 0) {
         atomicAdd(&p.counters[0], t);
         atomicAdd(&p.counters[1], s);
+#ifdef RT_STAMPS
+        atomicAdd(&g_dbg[0], cyRefill);
+        atomicAdd(&g_dbg[1], cyScan);
+        atomicAdd(&g_dbg[2], cyTrans);
+        atomicAdd(&g_dbg[3], cyIters);
+        atomicAdd(&g_dbg[4], dbgScan[0]);
+        atomicAdd(&g_dbg[5], dbgScan[1]);
+        atomicAdd(&g_dbg[7], dbgScan[3]);
+#endif
     }
 }
 

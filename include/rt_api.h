@@ -205,6 +205,10 @@ int rt_unit_camera_rays(rt_ctx* ctx, const rt_camera* camera, const float* uv_of
  * out: scattered flag, attenuation 3, scattered direction 3, draws consumed, Emit+Shade 3 (11 floats). */
 int rt_unit_scatter(rt_ctx* ctx, const rt_material* material, const rt_light* sun, const float view_origin[3],
                     const float* in, uint32_t n, float* out);
+/* Host-only view of the clustered storage rt_scene_upload builds for the scan (groups of four spheres with a
+ * conservative bounding sphere each).  orig: 4 entries per group, 0xffffffff = padding;
+ * bounds: Cx, Cy, Cz, |C|^2 - Rf^2 per group.  cap_groups == 0 only queries *n_groups.  Needs no GPU. */
+int rt_unit_layout(const rt_sphere* spheres, uint32_t n, uint32_t cap_groups, uint32_t* n_groups, uint32_t* orig, float* bounds);
 /* The resolve of spheres-app.cpp:196-214 for given HDR triples -> R,G,B bytes */
 int rt_unit_tonemap(rt_ctx* ctx, const float* hdr_rgb, uint32_t n, uint32_t n_samples, uint8_t* out_rgb);
 

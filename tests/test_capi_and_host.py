@@ -100,3 +100,47 @@ def test_assemble_deinterleaves(built):
             pad = np.full((D.max_local_rows(H, world) - len(rows), W, 2), -1, dtype=np.float32)
             parts.append(np.concatenate([p, pad], 0))
         assert np.array_equal(D.assemble(parts, H, world), full)
+
+
+def _layout(spheres):
+    import ctypes as C
+    from cpuraytracer_amd import _capi
+    L = _capi.load()
+    n = C.c_uint32(0)
+    sph = np.ascontiguousarray(spheres)
+    _capi.check(L.rt_unit_layout(sph.ctypes.data, sph.shape[0], 0, C.byref(n), None, None))
+    orig = np.zeros(n.value * 4, dtype=np.uint32)
+    bounds = np.zeros((n.value, 4), dtype=np.float32)
+    _capi.check(L.rt_unit_layout(sph.ctypes.data, sph.shape[0], n.value, C.byref(n), orig.ctypes.data, bounds.ctypes.data))
+    return orig.reshape(-1, 4), bounds
+
+
+@pytest.mark.parametrize("name", ["cover", "three", "grid10k"])
+def test_clustered_layout_is_a_partition_with_enclosing_bounds(built, oracle, name):
+    """Every sphere appears in exactly one group, and each group's bound encloses its members with the margins
+    the filter's conservativeness argument needs."""
+    sc = oracle.build_scene(name, 1, 1.5)
+    orig, bounds = _layout(sc.spheres)
+    assert orig.shape[0] % 2 == 0
+    members = orig[orig != 0xFFFFFFFF]
+    assert sorted(members.tolist()) == list(range(sc.n))
+    c = np.stack([sc.spheres["cx"], sc.spheres["cy"], sc.spheres["cz"]], 1).astype(np.float64)
+    r = sc.spheres["r"].astype(np.float64)
+    keps = 2048 * 2.0 ** -24
+    for g in range(orig.shape[0]):
+        ids = orig[g][orig[g] != 0xFFFFFFFF]
+        if len(ids) == 0:
+            assert bounds[g, 3] >= 1e29  # padding group can never pass the filter
+            continue
+        C_ = bounds[g, :3].astype(np.float64)
+        s_i = np.linalg.norm(c[ids] - C_, axis=1)
+        R = (s_i + r[ids]).max()
+        Rf2 = float(C_ @ C_) - float(bounds[g, 3])
+        Cn = np.linalg.norm(C_)
+        need = R * R + 0.01 * s_i.max() ** 2 + keps * (2 * (Cn + R) ** 2 + R * R)
+        assert Rf2 >= need * (1 - 1e-9), (g, Rf2, need)
+    if name == "cover":
+        # compact groups: the k-d split keeps the small-sphere bounds under two grid cells
+        small = [g for g in range(orig.shape[0]) if (orig[g] != 0xFFFFFFFF).sum() > 1]
+        Rs = [np.sqrt(float(bounds[g, :3].astype(np.float64) @ bounds[g, :3].astype(np.float64)) - float(bounds[g, 3])) for g in small]
+        assert max(Rs) < 2.2

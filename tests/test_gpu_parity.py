@@ -254,6 +254,90 @@ def test_forced_global_tables_equal_lds_tables(hip, scenes_mod, monkeypatch):
     assert_same(a, b, "LDS-staged vs global-memory tables")
 
 
+# ----------------------------------------------- the scan's filter machinery
+def _custom_scene(oracle, centers, radii, types, cam_origin, cam_look, vfov, aspect, aperture=0.0):
+    """Flat scene from arrays (tests only): colours/smoothness fixed, camera via the oracle's Camera."""
+    n = len(radii)
+    sph = np.zeros(n, dtype=oracle.SPHERE_DTYPE)
+    sph["cx"], sph["cy"], sph["cz"], sph["r"] = centers[:, 0], centers[:, 1], centers[:, 2], radii
+    mat = np.zeros(n, dtype=oracle.MATERIAL_DTYPE)
+    k255 = np.float32(1) / np.float32(255)
+    mat["type"] = types
+    mat["smoothness"] = np.where(np.asarray(types) == 1, 0.0, 16.0)
+    mat["ior"] = 1.5
+    mat["rgb0"] = (np.array([200, 120, 60], dtype=np.float32) * k255)[None, :]
+    ref = oracle.build_scene("three", 1, aspect)
+    cam = oracle.RtCamera()
+    o = np.asarray(cam_origin, dtype=np.float64)
+    la = np.asarray(cam_look, dtype=np.float64)
+    oracle.lib().orc_camera_make((C.c_float * 3)(*o), (C.c_float * 3)(*la), vfov, aspect, float(np.linalg.norm(o - la)), aperture,
+                                 C.byref(cam))
+    return oracle.Scene(sph, mat, cam, ref.sun, ref.sky, ref.exposure_scale, "custom", 0)
+
+
+def _assert_image_equals_oracle(hip, oracle, sc, W, H, spp, depth, seed=3):
+    hip.upload(sc)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    sg = hip.render(W, H, 1, 1 + spp, depth, seed)
+    hg, _ = hip.download(ldr=False)
+    so = orc.render(W, H, 1, 1 + spp, depth, seed, accel=oracle.ACCEL_BVH, threads=8)
+    ho, _ = orc.download()
+    assert_same(hg, ho, "custom scene HDR")
+    assert sg.traversals == so.traversals and sg.segments == so.segments
+
+
+def test_matrix_core_scan_equals_valu_scan(hip, scenes_mod, monkeypatch):
+    """RT_SCAN=valu (no MFMA filter) and the default matrix-core scan give the same bits."""
+    from cpuraytracer_amd import HipRenderer
+    sc = scenes_mod.build_scene("cover", 1, 160, 104)
+    hip.upload(sc)
+    sa = hip.render(160, 104, 1, 5, 50, 1)
+    a, _ = hip.download(ldr=False)
+    monkeypatch.setenv("RT_SCAN", "valu")
+    r2 = HipRenderer(0)
+    r2.upload(sc)
+    sb = r2.render(160, 104, 1, 5, 50, 1)
+    b, _ = r2.download(ldr=False)
+    r2.close()
+    assert_same(a, b, "matrix-core scan vs VALU scan")
+    assert sa.traversals == sb.traversals
+
+
+def test_candidate_list_overflow_falls_back_exactly(hip, oracle):
+    """A ray skimming a long row of spheres passes the filter for far more groups than a candidate sub-list holds
+    (14): the owner lane must then resolve every group, and the image must still equal the oracle's."""
+    n = 240
+    centers = np.stack([np.arange(n) * 0.5 - 30.0, np.zeros(n), np.full(n, 5.0)], 1).astype(np.float32)
+    centers = np.concatenate([centers, [[0.0, -1000.2, 5.0]]]).astype(np.float32)
+    radii = np.concatenate([np.full(n, 0.2), [1000.0]]).astype(np.float32)
+    types = np.concatenate([np.tile([0, 1, 2], n // 3), [0]]).astype(np.uint32)
+    # camera far to the side looking ALONG the row: primary rays cross dozens of group bounds
+    sc = _custom_scene(oracle, centers, radii, types, (-45.0, 0.05, 5.0), (30.0, 0.0, 5.0), 8.0, 2.0)
+    _assert_image_equals_oracle(hip, oracle, sc, 96, 48, 2, 12)
+
+
+@pytest.mark.parametrize("offset,scale", [((5000.0, -3000.0, 7000.0), 1.0), ((0.0, 0.0, 0.0), 0.01), ((300.0, 50.0, -200.0), 40.0)])
+def test_filter_margins_hold_far_from_the_origin_and_at_odd_scales(hip, oracle, offset, scale):
+    """The filter's rounding margin scales with |o|^2 and |C|^2: translate/scale a random cluster so that those
+    terms dominate the sphere sizes and check that no hit is lost (image == oracle, bit for bit)."""
+    rng = np.random.default_rng(9)
+    n = 150
+    base = rng.uniform(-6, 6, size=(n, 3))
+    base[:, 1] = np.abs(base[:, 1]) * 0.3
+    radii = rng.uniform(0.05, 0.6, n)
+    centers = (base * scale + np.asarray(offset)).astype(np.float32)
+    radii = (radii * scale).astype(np.float32)
+    floor_c = (np.array([0.0, -500.0, 0.0]) * scale + np.asarray(offset)).astype(np.float32)
+    centers = np.concatenate([centers, floor_c[None, :]]).astype(np.float32)
+    radii = np.concatenate([radii, [np.float32(499.7 * scale)]]).astype(np.float32)
+    types = np.concatenate([rng.integers(0, 3, n), [0]]).astype(np.uint32)
+    cam_o = np.array([9.0, 2.0, -7.0]) * scale + np.asarray(offset)
+    cam_l = np.array([0.0, 0.5, 0.0]) * scale + np.asarray(offset)
+    sc = _custom_scene(oracle, centers, radii, types, cam_o, cam_l, 40.0, 1.5, aperture=0.05 * scale)
+    _assert_image_equals_oracle(hip, oracle, sc, 120, 80, 2, 20)
+
+
 # ------------------------------------------- properties at BASELINE.json's full size (C2)
 @pytest.fixture(scope="module")
 def c2_full(hip, scenes_mod):

@@ -1,0 +1,22 @@
+"""Diagnostic: section clocks of the trace megakernel (librt_hip_stamps.so, built with -DRT_STAMPS)."""
+import ctypes as C, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cpuraytracer_amd import _capi
+_capi.LIB_PATH = os.path.join(ROOT, "cpuraytracer_amd", "lib", "librt_hip_stamps.so")
+from cpuraytracer_amd import HipRenderer, scenes
+r = HipRenderer(0)
+r.upload(scenes.build_scene("cover", 1, 1200, 800))
+L = _capi.load()
+out = (C.c_ulonglong * 8)()
+L.rt_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+r.render(1200, 800, 1, 17, 50, 1)
+L.rt_debug_stamps(r._h, out)
+st = r.render(1200, 800, 1, 33, 50, 1)
+L.rt_debug_stamps(r._h, out)
+v = list(out)
+tot = v[0] + v[1] + v[2]
+print(json.dumps({"wave_iterations": v[3], "cycles_per_iteration": tot / v[3], "share_refill": v[0] / tot, "share_scan": v[1] / tot,
+                  "share_transitions_hit": v[2] / tot, "scan_filter_share": v[4] / (v[4] + v[5]), "scan_resolve_share": v[5] / (v[4] + v[5]),
+                  "resolve_items_per_ray_scan": v[6] / st.traversals, "resolve_max_items_per_wave_iteration": v[7] / v[3],
+                  "lanes_live_per_iteration": st.traversals / v[3], "ms_trace_stamped_build": st.ms_render}))
