@@ -172,10 +172,14 @@ def main():
                                    % (n_spheres, SCENE_SEED, W_IMG, H_IMG, spp, DEPTH, RENDER_SEED, N),
                        "spp_per_gpu": SPP_PER_GPU, "samples_per_step": total_samples,
                        "traversals_per_sample": avg_trav / (W_IMG * rows * spp)},
-            "roofline": {"bound": "valu", "kernel": "rt_trace_kernel<LDS tables>", "achieved": achieved_tflops,
-                         "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_VALU_TFLOPS,
-                         "traffic": traffic, "launch_ms": avg_ms,
-                         "algorithmic": "18 flop x %d spheres x %.0f list scans per launch (unfused fp32; peak = 157.3/2)" % (n_spheres, avg_trav)},
+            "roofline": {"bound": "valu", "kernel": "rt_trace_kernel<LDS tables, 1024 threads, matrix-core filter>",
+                         "achieved": achieved_tflops, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tflops / PEAK_VALU_TFLOPS, "traffic": traffic, "launch_ms": avg_ms,
+                         "algorithmic": "18 flop x %d spheres x %.0f list scans per launch (SURVEY.md 8d; unfused fp32, peak = 157.3/2)"
+                                        % (n_spheres, avg_trav),
+                         "note": "frac > 1 is real: ALGORITHMIC flops of an exhaustive list scan over the time of a kernel that culls "
+                                 "(group-bound filter on the matrix cores + exact VALU resolve of the survivors). Executed-instruction "
+                                 "view: profiles/r01_pmc_summary.json (VALU issue ~63 % busy, f32 MFMA ~16 %)"},
             "hbm_read_equivalent": {"bound": "hbm", "achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": achieved_gbs / PEAK_HBM_GBS,
                                     "note": "16 B sphere record x tests / kernel time; served from LDS, so it may exceed the HBM roofline"},

@@ -4,25 +4,28 @@
 //   GenerateRays            spheres-app.cpp:132-161  -> gen_primary_ray()           (in-register, never materialised)
 //   for_each(par) trace     spheres-app.cpp:177-184  -> rt_trace_kernel             (persistent-threads megakernel)
 //   GetHitColor recursion   spheres-app.cpp:238-257  -> per-lane state machine in rt_trace_kernel
-//   BvhNode/Sphere::Intersect ray-tracing.cpp:42-84,174-214 -> scan_list()          (LDS list scan, closest hit)
+//   BvhNode/Sphere::Intersect ray-tracing.cpp:42-84,174-214 -> scan_list_mfma() / scan_list_deferred() + resolve_group()
 //   Material::Scatter x3    material.cpp:20-164      -> scatter_and_shade()
 //   DirectionalLight::Shade light.cpp:11-42          -> scatter_and_shade() + the shadow scan
 //   hdr[id] += L*exposure   spheres-app.cpp:182-183  -> rt_accumulate_kernel        (ordered in s)
 //   tonemap transform(par)  spheres-app.cpp:196-214  -> rt_resolve_kernel
 //
-// Design (DESIGN.md has the long form):
+// Design (DESIGN.md §5 has the long form and the conservativeness argument):
 //   * one work-item per (pixel, sample) PATH; a wave keeps 64 paths in flight and refills finished
 //     lanes from a global queue by ballot + prefix count, so lanes stay full despite path lengths
 //     of 1..102 list scans;
 //   * a lane is always in one of two states, "needs closest-hit scan" or "needs shadow scan"; both
-//     run the SAME list scan, so every wave iteration is one scan with all 64 lanes doing useful
-//     intersection arithmetic (the shade value is computed before the shadow scan and added after
-//     it only if the sun is visible — same numbers as the reference's order, no state to carry);
-//   * the sphere list (cx,cy,cz,r^2), radii and material table are staged into LDS once per
-//     workgroup; the scan reads one sphere per ds_read_b128 at a wave-uniform address (broadcast).
-//     Measured on MI355X (profiles/r01_valu_rate2_microbench.jsonl): a VALU op with an SGPR source
-//     issues at half rate, so sphere data must arrive in VGPRs — LDS broadcast, not s_load;
-//   * xoshiro128** state in 4 VGPRs per lane; no MFMA (branchy scalar FP32, 3-term dot products);
+//     run the SAME closest-hit search, so every wave iteration is one scan for 64 useful rays (the
+//     shade value is computed before the shadow scan and added after it only if the sun is visible —
+//     same numbers as the reference's order, no state to carry);
+//   * the scan is a conservative FILTER followed by an EXACT resolve.  Spheres are stored in k-d
+//     groups of four with a bounding sphere each; "which ray may hit which group" is a K = 4 dense
+//     contraction evaluated on the matrix cores (v_mfma_f32_32x32x2_f32), survivors are appended to
+//     per-ray candidate lists in LDS, and every lane then evaluates Sphere::Intersect in the
+//     reference's operation order for its own candidates only.  The image equals an exhaustive scan
+//     bit for bit; scene tables, operand image and candidate lists live in LDS (measured: VALU ops
+//     with SGPR sources issue at half rate on gfx950, so scene data must arrive in VGPRs);
+//   * xoshiro128** state in 4 VGPRs per lane;
 //   * per-path results go to an HBM sample buffer [pixel][s] (12 B each) and are summed in
 //     increasing s by rt_accumulate_kernel: the reference's summation order, bit for bit.
 #pragma once
