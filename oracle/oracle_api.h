@@ -28,6 +28,8 @@ int orc_scene_upload(orc_ctx* ctx, const rt_sphere* spheres, const rt_material* 
                      const rt_camera* camera, const rt_light* sun, const rt_material* sky, float exposure_scale);
 int orc_render(orc_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1, uint32_t max_depth,
                uint64_t seed, int accel, int threads, rt_stats* out_stats);
+/* N3: drive material draws from the reference's per-material Halton counters (serial renders only) */
+void orc_use_reference_halton_counters(int on);
 int orc_clear(orc_ctx* ctx);
 int orc_resolve(orc_ctx* ctx, uint32_t n_samples);
 int orc_download(orc_ctx* ctx, float* hdr_rgb, uint8_t* ldr_rgb);

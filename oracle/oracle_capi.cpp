@@ -64,6 +64,7 @@ int orc_render(orc_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, 
     if (!ctx || W == 0 || H == 0 || s1 <= s0 || s0 == 0) return Fail("orc_render: invalid argument");
     if (!ctx->app.HasScene()) return Fail("orc_render: no scene");
     if (RowsetLocalRows(rs) == 0 || rs.first_row + rs.num_rows > H) return Fail("orc_render: bad row set");
+    if (Random::ReferenceHaltonCounters() && threads > 1) return Fail("orc_render: the reference-counter sampler is serial only");
     if (s0 == 1) ctx->app.Clear();
     else if (ctx->app.SampleCount() + 1 != s0) return Fail("orc_render: sample range does not continue the accumulation");
     RenderCounters rc;
@@ -79,6 +80,8 @@ int orc_render(orc_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, 
     }
     return 0;
 }
+
+void orc_use_reference_halton_counters(int on) { Random::UseReferenceHaltonCounters(on != 0); }
 
 int orc_clear(orc_ctx* ctx) {
     if (!ctx) return Fail("orc_clear: null ctx");

@@ -73,6 +73,20 @@ float NextMaterialDraw() {
     return t_stream->NextUniform();
 }
 
+static bool g_refCounters = false;
+void UseReferenceHaltonCounters(bool on) { g_refCounters = on; }
+bool ReferenceHaltonCounters() { return g_refCounters; }
+float Draw(uint64_t& counter, uint32_t base) {
+    if (g_refCounters && !t_script) return HaltonSample(counter++, base);
+    return NextMaterialDraw();
+}
+XMFLOAT3 DrawHemisphere(uint64_t& counter, uint32_t base1, uint32_t base2) {
+    if (g_refCounters && !t_script) return HaltonSampleHemisphere(counter++, base1, base2);
+    const float u1 = NextMaterialDraw();  // the two Halton dimensions, in that order
+    const float u2 = NextMaterialDraw();
+    return HemisphereFromUniforms(u1, u2);
+}
+
 }  // namespace Random
 
 static thread_local uint64_t t_traversals = 0;
@@ -308,7 +322,7 @@ bool DielectricOpaque::Scatter(const Ray& ray, const Payload& hit, XMVECTOR& out
         XMVECTOR nDotV = XMVectorSaturate(XMVector3Dot(-ray.direction, hit.normal));
         XMVECTOR reflectance = f0 + (ORC_XM_One - f0) * XMVectorPow(ORC_XM_One - nDotV, XMVectorReplicate(5.f));
 
-        const XMVECTOR rand = XMVectorReplicate(Random::NextMaterialDraw());  // was HaltonSample(counter++, 3), :29
+        const XMVECTOR rand = XMVectorReplicate(Random::Draw(m_reflectionProbabilitySampleIndex, 3));  // :29
         bool bReflect = XMVector3Greater(reflectance, rand);
 
         if (bReflect) {
@@ -319,10 +333,8 @@ bool DielectricOpaque::Scatter(const Ray& ray, const Payload& hit, XMVECTOR& out
         } else {
             outAttenuation = m_albedo->Evaluate(hit.uv);
 
-            // was HaltonSampleHemisphere(counter++, 5, 7), :44 — two draws (u1, u2) in that order
-            const float u1 = Random::NextMaterialDraw();
-            const float u2 = Random::NextMaterialDraw();
-            XMFLOAT3 dir = Random::HemisphereFromUniforms(u1, u2);
+            // HaltonSampleHemisphere(counter++, 5, 7), :44 — with the path stream: two draws (u1, u2) in that order
+            XMFLOAT3 dir = Random::DrawHemisphere(m_sampleIndex, 5, 7);
 
             XMVECTOR b3 = hit.normal;
             XMFLOAT3 temp;
@@ -351,7 +363,7 @@ bool Metal::Scatter(const Ray& ray, const Payload& hit, XMVECTOR& outAttenuation
         XMVECTOR reflectance = f0 + (ORC_XM_One - f0) * XMVectorPow(ORC_XM_One - nDotV, XMVectorReplicate(5.f));
 
         uint32_t bReflect;
-        const XMVECTOR rand = XMVectorReplicate(Random::NextMaterialDraw());  // was HaltonSample(counter++, 3), :82
+        const XMVECTOR rand = XMVectorReplicate(Random::Draw(m_reflectionProbabilitySampleIndex, 3));  // :82
         XMVectorGreaterR(&bReflect, reflectance, rand);
 
         if (XMComparisonAnyTrue(bReflect)) {
@@ -400,7 +412,7 @@ bool DielectricTransparent::Scatter(const Ray& ray, const Payload& hit, XMVECTOR
         reflectionProbability = ORC_XM_One;
     }
 
-    const XMVECTOR rand = XMVectorReplicate(Random::NextMaterialDraw());  // was HaltonSample(counter++, 7), :151
+    const XMVECTOR rand = XMVectorReplicate(Random::Draw(m_sampleIndex, 7));  // :151
 
     if (XMVector3Greater(reflectionProbability, rand)) {
         const XMVECTOR reflectDir = XMVector3Normalize(XMVector3Reflect(ray.direction, hit.normal));

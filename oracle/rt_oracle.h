@@ -76,6 +76,14 @@ XMFLOAT3 HemisphereFromUniforms(float u1, float u2);
 // The path's material draw stream (replaces `counter++` -> HaltonSample at material.cpp:29,44,82,151).
 void BindPathStream(Xoshiro128* stream);
 float NextMaterialDraw();
+// Reference-faithful sampler mode: when enabled, a material draw is
+// HaltonSample(counter++, base) on the material's own counter exactly as material.cpp:29,44,82,151 do —
+// only meaningful for a SERIAL render (the reference's counters are racy under its thread pool).  Used by the
+// statistical parity test; the deterministic per-path stream stays the contract for the GPU parity tests.
+void UseReferenceHaltonCounters(bool on);
+bool ReferenceHaltonCounters();
+float Draw(uint64_t& counter, uint32_t base);                                      // one uniform
+XMFLOAT3 DrawHemisphere(uint64_t& counter, uint32_t base1, uint32_t base2);        // quasi-random.cpp:36-50
 // Unit tests only: replay caller-provided uniforms instead of the bound stream.
 void ScriptDraws(const float* draws, uint32_t n);
 uint32_t ScriptDrawsUsed();
@@ -209,6 +217,7 @@ public:
 private:
     const Texture* m_reflectance;
     XMVECTOR m_smoothness;
+    mutable uint64_t m_reflectionProbabilitySampleIndex = 0u;  // material.h:34 (std::atomic there)
 };
 class DielectricOpaque : public Material {  // material.h:37-52
 public:
@@ -221,6 +230,8 @@ public:
 private:
     const Texture* m_albedo;
     XMVECTOR m_smoothness;
+    mutable uint64_t m_sampleIndex = 0u;                       // material.h:50
+    mutable uint64_t m_reflectionProbabilitySampleIndex = 0u;  // material.h:51
 };
 class DielectricTransparent : public Material {  // material.h:54-68
 public:
@@ -233,6 +244,7 @@ public:
 private:
     XMVECTOR m_smoothness;
     XMVECTOR m_ior;
+    mutable uint64_t m_sampleIndex = 0u;  // material.h:67
 };
 class Emissive : public Material {  // material.h:70-84
 public:

@@ -441,3 +441,38 @@ def test_depth_limit_and_seed_sensitivity(oracle):
     a, _ = orc.trace(1200, 800, ijs, 50, 1)
     b, _ = orc.trace(1200, 800, ijs, 50, 2)
     assert not np.array_equal(a, b)
+
+
+def test_statistical_parity_with_the_reference_halton_counter_sampler(oracle):
+    """SURVEY.md §4 'Statistical' / §8f N3: the estimator driven by the reference's own per-material global Halton
+    counters (material.h:34,50-51,67; serial, so not racy) and the per-path xoshiro estimator converge to the same
+    image.  Per-pixel parity with the original is impossible; agreement within Monte-Carlo error is
+    what 'same estimator' means."""
+    sc = oracle.build_scene("cover", 1, 1.5)
+    W, H, spp = 60, 40, 192
+    try:
+        oracle.lib().orc_use_reference_halton_counters(1)
+        orc = oracle.Oracle()
+        orc.upload(sc)  # fresh materials: counters start at 0 like a fresh process
+        orc.render(W, H, 1, 1 + spp, 50, 1, accel=oracle.ACCEL_BVH, threads=1)
+        ref, _ = orc.download()
+        with pytest.raises(RuntimeError):
+            orc.render(W, H, 1, 2, 50, 1, threads=2)
+    finally:
+        oracle.lib().orc_use_reference_halton_counters(0)
+    imgs = []
+    for seed in (1, 2):
+        orc = oracle.Oracle()
+        orc.upload(sc)
+        orc.render(W, H, 1, 1 + spp, 50, seed, accel=oracle.ACCEL_BVH, threads=4)
+        imgs.append(orc.download()[0])
+    a, b = imgs
+    ref, a, b = ref / spp, a / spp, b / spp
+    # image means agree to a percent; the two xoshiro seeds set the Monte-Carlo noise scale
+    assert np.allclose(ref.mean(axis=(0, 1)), a.mean(axis=(0, 1)), rtol=0.02)
+    noise = np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(2)  # per-pixel std of one estimate
+    rms = np.sqrt(np.mean((ref - a) ** 2))
+    assert rms < 2.0 * noise, (rms, noise)
+    # and 8x8-block averages (noise / 8) agree much more tightly than single pixels
+    blk = lambda x: x[:40, :56].reshape(5, 8, 7, 8, 3).mean(axis=(1, 3))
+    assert np.max(np.abs(blk(ref) - blk(a))) < 8.0 * noise / 8.0 + 0.01 * blk(a).max()
