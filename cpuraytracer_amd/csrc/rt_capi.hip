@@ -73,7 +73,7 @@ struct rt_ctx {
     // scene
     bool hasScene = false;
     uint32_t n = 0;
-    DevBuf<float4> scan, bounds;
+    DevBuf<float4> scan, tree;
     DevBuf<uint32_t> orig;
     DevBuf<float> radius;
     DevBuf<rt_material> mats;
@@ -95,6 +95,7 @@ struct rt_ctx {
     uint32_t blocksPerCu = 4;
     uint32_t blockThreads = 256;
     bool useMfma = true;  // matrix-core pre-filter for the list scan (RT_SCAN=valu disables)
+    uint32_t treeTop = 128;  // largest top level the matrix-core filter takes (4 tiles of 32); RT_TREE_TOP overrides
     bool forceGlobal = false;
 };
 
@@ -116,12 +117,44 @@ static uint32_t RowsetLocalRows(rt_rowset rs) {
 struct SceneLayout {
     std::vector<float4> scan;     // 4 * nGroups + 4 entries
     std::vector<uint32_t> orig;   // same length
-    std::vector<float4> bounds;   // nGroups
-    uint32_t nGroups = 0;
+    std::vector<float4> tree;     // bounds of every level, level 0 (the groups) first
+    uint32_t levelOff[rtd::kMaxLevels] = {0}, levelCnt[rtd::kMaxLevels] = {0};
+    uint32_t nLevels = 1;         // level nLevels-1 is the top level (<= topMax nodes), filtered on the matrix cores
+    uint32_t nGroups = 0;         // = levelCnt[0], a multiple of 4
     float boundNorm = 0.f;        // max |C| + R
 };
 
-static void BuildLayout(const rt_sphere* sp, uint32_t n, SceneLayout& L) {
+// Conservative bounding sphere of a set of spheres, in the filter's (C, |C|^2 - Rf^2) form.
+static float4 BoundOf(const rt_sphere* sp, const std::vector<uint32_t>& ids, float* normOut) {
+    if (ids.empty()) return make_float4(0.f, 0.f, 0.f, 1e30f);  // never a candidate
+    const double kEps = 2048.0 * 5.9604644775390625e-08;  // K * eps, K = 2048 (rt_kernels.h kMarginRel)
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t k : ids) {
+        const double c[3] = {sp[k].cx, sp[k].cy, sp[k].cz};
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], c[a] - (double)sp[k].r);
+            hi[a] = std::max(hi[a], c[a] + (double)sp[k].r);
+        }
+    }
+    // the bound centre is the FLOAT the device will use, so its rounding is inside s_i below
+    const float Cf[3] = {(float)(0.5 * (lo[0] + hi[0])), (float)(0.5 * (lo[1] + hi[1])), (float)(0.5 * (lo[2] + hi[2]))};
+    double R = 0, smax = 0;
+    for (uint32_t k : ids) {
+        const double dx = sp[k].cx - (double)Cf[0], dy = sp[k].cy - (double)Cf[1], dz = sp[k].cz - (double)Cf[2];
+        const double si = std::sqrt(dx * dx + dy * dy + dz * dz);
+        smax = std::max(smax, si);
+        R = std::max(R, si + (double)sp[k].r);
+    }
+    const double C2 = (double)Cf[0] * Cf[0] + (double)Cf[1] * Cf[1] + (double)Cf[2] * Cf[2];
+    const double Cn = std::sqrt(C2);
+    const double Rf2 = R * R * (1.0 + 1e-5) + 0.01 * smax * smax + kEps * (2.0 * (Cn + R) * (Cn + R) + R * R);
+    float w = (float)(C2 - Rf2);
+    w = std::nextafterf(std::nextafterf(w, -INFINITY), -INFINITY);  // err towards "more candidates"
+    if (normOut) *normOut = std::max(*normOut, (float)((Cn + R) * 1.001));
+    return make_float4(Cf[0], Cf[1], Cf[2], w);
+}
+
+static void BuildLayout(const rt_sphere* sp, uint32_t n, uint32_t topMax, SceneLayout& L) {
     std::vector<float> radii(n);
     for (uint32_t k = 0; k < n; ++k) radii[k] = sp[k].r;
     std::vector<float> sorted = radii;
@@ -129,10 +162,12 @@ static void BuildLayout(const rt_sphere* sp, uint32_t n, SceneLayout& L) {
     const float median = sorted[n / 2];
     std::vector<uint32_t> big, small;
     for (uint32_t k = 0; k < n; ++k) (radii[k] > 4.f * median ? big : small).push_back(k);
-    // k-d median split down to leaves of four: compact, balanced groups (Morton chunks of a jittered grid
-    // have 3x the summed R^2 and twice the filter candidates; tools/cluster_eval.py)
+    // k-d median split down to leaves of four, emitted in tree order: compact, balanced groups whose
+    // neighbours in the list are neighbours in space (Morton chunks of a jittered grid have 3x the summed R^2
+    // and twice the filter candidates; tools/cluster_eval.py)
     std::vector<std::vector<uint32_t>> groups;
     for (uint32_t k : big) groups.push_back({k});
+    while (!big.empty() && (groups.size() & 3u)) groups.push_back({});  // big spheres keep upper-level nodes of their own
     std::vector<std::pair<size_t, size_t>> stack;  // [begin, end) ranges of `small`
     if (!small.empty()) stack.push_back({0, small.size()});
     while (!stack.empty()) {
@@ -157,49 +192,47 @@ static void BuildLayout(const rt_sphere* sp, uint32_t n, SceneLayout& L) {
             const float cx[3] = {sp[x].cx, sp[x].cy, sp[x].cz}, cy[3] = {sp[y].cx, sp[y].cy, sp[y].cz};
             return cx[ax] < cy[ax];
         });
-        size_t half = ((e - b) / 2 + 3) / 4 * 4;  // left part a multiple of four
+        // left part: the largest power-of-four multiple of 4 not above half, so whole subtrees stay aligned
+        size_t half = ((e - b) / 2 + 3) / 4 * 4;
+        size_t p4 = 4;
+        while (p4 * 4 <= (e - b) / 2 + 3) p4 *= 4;
+        if (p4 >= 16 && (e - b) > p4) half = std::max(p4, (size_t)(((e - b) / 2) / p4 * p4));
         if (half >= e - b) half = (e - b) / 2;
         stack.push_back({b + half, e});
         stack.push_back({b, b + half});
     }
-    if (groups.size() & 1u) groups.push_back({});  // the VALU scan walks two groups per iteration
+    while (groups.size() & 3u) groups.push_back({});  // whole nodes at the next level; also even for the VALU scan
     L.nGroups = (uint32_t)groups.size();
     const float4 never = make_float4(0.f, 0.f, 0.f, -1e30f);  // r*r = -1e30: discriminant negative for any ray
     L.scan.assign((size_t)L.nGroups * 4 + 4, never);
     L.orig.assign((size_t)L.nGroups * 4 + 4, 0xffffffffu);
-    L.bounds.assign(L.nGroups, make_float4(0.f, 0.f, 0.f, 1e30f));
-    const double kEps = 2048.0 * 5.9604644775390625e-08;  // K * eps, K = 2048 (rt_kernels.h kMarginRel)
     for (uint32_t gi = 0; gi < L.nGroups; ++gi) {
-        const auto& g = groups[gi];
-        if (g.empty()) continue;
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (uint32_t k : g) {
-            const double c[3] = {sp[k].cx, sp[k].cy, sp[k].cz};
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = std::min(lo[a], c[a]);
-                hi[a] = std::max(hi[a], c[a]);
-            }
-        }
-        // the bound centre is the FLOAT the device will use, so its rounding is inside s_i below
-        const float Cf[3] = {(float)(0.5 * (lo[0] + hi[0])), (float)(0.5 * (lo[1] + hi[1])), (float)(0.5 * (lo[2] + hi[2]))};
-        double R = 0, smax = 0;
-        for (size_t m = 0; m < g.size(); ++m) {
-            const uint32_t k = g[m];
-            const double dx = sp[k].cx - (double)Cf[0], dy = sp[k].cy - (double)Cf[1], dz = sp[k].cz - (double)Cf[2];
-            const double si = std::sqrt(dx * dx + dy * dy + dz * dz);
-            smax = std::max(smax, si);
-            R = std::max(R, si + (double)sp[k].r);
+        for (size_t m = 0; m < groups[gi].size(); ++m) {
+            const uint32_t k = groups[gi][m];
             // radius * radius is the float product Sphere::Intersect forms per call (ray-tracing.cpp:48)
             L.scan[(size_t)gi * 4 + m] = make_float4(sp[k].cx, sp[k].cy, sp[k].cz, sp[k].r * sp[k].r);
             L.orig[(size_t)gi * 4 + m] = k;
         }
-        const double C2 = (double)Cf[0] * Cf[0] + (double)Cf[1] * Cf[1] + (double)Cf[2] * Cf[2];
-        const double Cn = std::sqrt(C2);
-        const double Rf2 = R * R * (1.0 + 1e-5) + 0.01 * smax * smax + kEps * (2.0 * (Cn + R) * (Cn + R) + R * R);
-        float w = (float)(C2 - Rf2);
-        w = std::nextafterf(std::nextafterf(w, -INFINITY), -INFINITY);  // err towards "more candidates"
-        L.bounds[gi] = make_float4(Cf[0], Cf[1], Cf[2], w);
-        L.boundNorm = std::max(L.boundNorm, (float)((Cn + R) * 1.001));
+    }
+    // levels: level 0 = the groups; level k+1 node j = level-k nodes 4j .. 4j+3; stop at <= topMax nodes
+    std::vector<std::vector<uint32_t>> members = groups;
+    L.tree.clear();
+    L.nLevels = 0;
+    for (;;) {
+        const uint32_t lvl = L.nLevels++;
+        L.levelOff[lvl] = (uint32_t)L.tree.size();
+        L.levelCnt[lvl] = (uint32_t)members.size();
+        for (const auto& ids : members) L.tree.push_back(BoundOf(sp, ids, &L.boundNorm));
+        if (members.size() <= topMax || L.nLevels == rtd::kMaxLevels) break;
+        while (members.size() & 3u) {  // pad this level to whole parents
+            members.push_back({});
+            L.tree.push_back(BoundOf(sp, {}, nullptr));
+            L.levelCnt[lvl] += 1;
+        }
+        std::vector<std::vector<uint32_t>> up(members.size() / 4);
+        for (size_t j = 0; j < up.size(); ++j)
+            for (int q = 0; q < 4; ++q) up[j].insert(up[j].end(), members[4 * j + q].begin(), members[4 * j + q].end());
+        members.swap(up);
     }
 }
 static size_t LdsBytesFor(uint32_t n, uint32_t nPadded) { return (size_t)nPadded * (16 + 4) + (size_t)n * 48 + (size_t)((n + 3) / 4) * 16; }
@@ -218,10 +251,13 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     uint32_t blocks = (uint32_t)((wavesNeeded + wavesPerBlock - 1) / wavesPerBlock);
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks == 0) blocks = 1;
-    // dynamic LDS: per-wave candidate regions + the scene tables when they fit (+ the filter operand image)
-    const size_t candBytes = (size_t)wavesPerBlock * 3840;
-    const bool mfma = useLds && ctx->useMfma && (candBytes + lds + MfmaOpsBytesFor(tp.n_groups)) <= 160 * 1024;
-    const size_t ldsBytes = candBytes + (useLds ? lds : 0) + (mfma ? MfmaOpsBytesFor(tp.n_groups) : 0);
+    // dynamic LDS: per-wave candidate regions + the scene tables when they fit + the filter operand image
+    const bool tree = ctx->useMfma && tp.n_levels > 1;  // deeper hierarchy: tables stay in global memory (L2)
+    const uint32_t topCnt = tp.level_cnt[tp.n_levels - 1];
+    const size_t candBytes = (size_t)wavesPerBlock * (tree ? rtd::kWaveCandBytes : rtd::kWaveListBytes);
+    const bool flat = !tree && useLds && ctx->useMfma && (candBytes + lds + MfmaOpsBytesFor(topCnt)) <= 160 * 1024;
+    const bool ldsTables = useLds && !tree;
+    const size_t ldsBytes = candBytes + (ldsTables ? lds : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0);
 #define RT_LAUNCH(LDS, T, M)                                                                                                   \
     do {                                                                                                                      \
         if (ldsBytes > 48 * 1024)                                                                                             \
@@ -229,25 +265,19 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));                           \
         hipLaunchKernelGGL((rtd::rt_trace_kernel<LDS, T, M>), dim3(blocks), dim3(T), ldsBytes, ctx->stream, tp);              \
     } while (0)
-    if (mfma) {
-        if (ctx->blockThreads == 1024) RT_LAUNCH(true, 1024, true);
-        else if (ctx->blockThreads == 768) RT_LAUNCH(true, 768, true);
-        else if (ctx->blockThreads == 384) RT_LAUNCH(true, 384, true);
-        else if (ctx->blockThreads == 512) RT_LAUNCH(true, 512, true);
-        else RT_LAUNCH(true, 256, true);
-    } else if (useLds) {
-        if (ctx->blockThreads == 1024) RT_LAUNCH(true, 1024, false);
-        else if (ctx->blockThreads == 768) RT_LAUNCH(true, 768, false);
-        else if (ctx->blockThreads == 384) RT_LAUNCH(true, 384, false);
-        else if (ctx->blockThreads == 512) RT_LAUNCH(true, 512, false);
-        else RT_LAUNCH(true, 256, false);
-    } else {
-        if (ctx->blockThreads == 1024) RT_LAUNCH(false, 1024, false);
-        else if (ctx->blockThreads == 768) RT_LAUNCH(false, 768, false);
-        else if (ctx->blockThreads == 384) RT_LAUNCH(false, 384, false);
-        else if (ctx->blockThreads == 512) RT_LAUNCH(false, 512, false);
-        else RT_LAUNCH(false, 256, false);
-    }
+#define RT_LAUNCH_T(LDS, M)                                            \
+    do {                                                               \
+        if (ctx->blockThreads == 1024) RT_LAUNCH(LDS, 1024, M);        \
+        else if (ctx->blockThreads == 768) RT_LAUNCH(LDS, 768, M);     \
+        else if (ctx->blockThreads == 512) RT_LAUNCH(LDS, 512, M);     \
+        else if (ctx->blockThreads == 384) RT_LAUNCH(LDS, 384, M);     \
+        else RT_LAUNCH(LDS, 256, M);                                   \
+    } while (0)
+    if (tree) RT_LAUNCH_T(false, 2);
+    else if (flat) RT_LAUNCH_T(true, 1);
+    else if (ldsTables) RT_LAUNCH_T(true, 0);
+    else RT_LAUNCH_T(false, 0);
+#undef RT_LAUNCH_T
 #undef RT_LAUNCH
     RT_HIP(hipGetLastError());
     return RT_OK;
@@ -291,6 +321,8 @@ int rt_create(int device_ordinal, rt_ctx** out) {
     {
         const char* scan = std::getenv("RT_SCAN");
         ctx->useMfma = !(scan && std::strcmp(scan, "valu") == 0);
+        ctx->treeTop = EnvU32("RT_TREE_TOP", 128);
+        if (ctx->treeTop < 4 || ctx->treeTop > 128) ctx->treeTop = 128;
     }
     // launch geometry (sweeps: profiles/r01_sweep_*.jsonl): the matrix-core scan wants 16 waves per CU in ONE
     // 1024-thread workgroup (one LDS image, 128 VGPRs); the pure-VALU scan runs 4 x 256 threads
@@ -318,7 +350,7 @@ void rt_destroy(rt_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->scan.Release();
     ctx->orig.Release();
-    ctx->bounds.Release();
+    ctx->tree.Release();
     ctx->radius.Release();
     ctx->mats.Release();
     ctx->hdr.Release();
@@ -353,11 +385,11 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     RT_HIP(hipSetDevice(ctx->device));
     int rc;
     SceneLayout L;
-    BuildLayout(spheres, n, L);
+    BuildLayout(spheres, n, ctx->treeTop, L);
     const uint32_t nPad = (uint32_t)L.scan.size();
     if ((rc = ctx->scan.Reserve(nPad)) != RT_OK) return rc;
     if ((rc = ctx->orig.Reserve(nPad)) != RT_OK) return rc;
-    if ((rc = ctx->bounds.Reserve(L.nGroups)) != RT_OK) return rc;
+    if ((rc = ctx->tree.Reserve(L.tree.size())) != RT_OK) return rc;
     if ((rc = ctx->radius.Reserve(n)) != RT_OK) return rc;
     if ((rc = ctx->mats.Reserve(n)) != RT_OK) return rc;
     std::vector<float> rad(n);
@@ -365,7 +397,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     RT_HIP(hipStreamSynchronize(ctx->stream));
     RT_HIP(hipMemcpy(ctx->scan.ptr, L.scan.data(), nPad * sizeof(float4), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->orig.ptr, L.orig.data(), nPad * sizeof(uint32_t), hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(ctx->bounds.ptr, L.bounds.data(), L.nGroups * sizeof(float4), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->tree.ptr, L.tree.data(), L.tree.size() * sizeof(float4), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->radius.ptr, rad.data(), n * sizeof(float), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->mats.ptr, materials, n * sizeof(rt_material), hipMemcpyHostToDevice));
 
@@ -373,8 +405,13 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     b = rtd::TraceParams{};
     b.scan = ctx->scan.ptr;
     b.orig = ctx->orig.ptr;
-    b.bounds = ctx->bounds.ptr;
+    b.tree = ctx->tree.ptr;
     b.n_groups = L.nGroups;
+    b.n_levels = L.nLevels;
+    for (uint32_t k = 0; k < rtd::kMaxLevels; ++k) {
+        b.level_off[k] = L.levelOff[k];
+        b.level_cnt[k] = L.levelCnt[k];
+    }
     b.bound_norm = L.boundNorm;
     b.radius = ctx->radius.ptr;
     b.mats = ctx->mats.ptr;
@@ -741,12 +778,12 @@ int rt_unit_tonemap(rt_ctx* ctx, const float* hdr_rgb, uint32_t n, uint32_t n_sa
 int rt_unit_layout(const rt_sphere* spheres, uint32_t n, uint32_t cap_groups, uint32_t* n_groups, uint32_t* orig, float* bounds) {
     if (!spheres || n == 0 || !n_groups) return Fail(RT_ERR_INVALID_ARG, "rt_unit_layout: invalid argument");
     SceneLayout L;
-    BuildLayout(spheres, n, L);
+    BuildLayout(spheres, n, 128, L);
     *n_groups = L.nGroups;
     if (cap_groups == 0) return RT_OK;
     if (cap_groups < L.nGroups || !orig || !bounds) return Fail(RT_ERR_INVALID_ARG, "rt_unit_layout: capacity too small");
     std::memcpy(orig, L.orig.data(), (size_t)L.nGroups * 4 * sizeof(uint32_t));
-    std::memcpy(bounds, L.bounds.data(), (size_t)L.nGroups * sizeof(float4));
+    std::memcpy(bounds, L.tree.data(), (size_t)L.nGroups * sizeof(float4));  // level 0 comes first
     return RT_OK;
 }
 

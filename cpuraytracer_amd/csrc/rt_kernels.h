@@ -57,6 +57,7 @@ RT_DEV unsigned long long rt_stamp() {
 #endif
 
 constexpr int kWaveSize = 64;
+constexpr uint32_t kMaxLevels = 6;  // levels of group bounds (4-ary): 128 * 4^5 groups at most
 constexpr uint32_t kQueueBlock = 256;  // paths a wave takes from the global queue per atomic
 
 struct TraceParams {
@@ -66,7 +67,11 @@ struct TraceParams {
     // update breaks ties by the ORIGINAL list index (orig[]).
     const float4* scan;        // [n_padded] cx, cy, cz, r*r in clustered order (padding: never-hit entries, r*r = -1e30)
     const uint32_t* orig;      // [n_padded] original list index of each entry (0xffffffff for padding)
-    const float4* bounds;      // [n_groups] group bound for the filter: Cx, Cy, Cz, |C|^2 - Rf^2
+    // Bounds hierarchy (4-ary): level 0 = the groups, level k+1 node j = level-k nodes 4j..4j+3; the top level
+    // (<= 128 nodes) is filtered on the matrix cores, lower levels are descended per lane.
+    const float4* tree;        // all levels, level 0 first: Cx, Cy, Cz, |C|^2 - Rf^2
+    uint32_t level_off[kMaxLevels], level_cnt[kMaxLevels];
+    uint32_t n_levels;
     const float* radius;       // [n] by original index
     const rt_material* mats;   // [n] by original index
     uint32_t n;                // real spheres
@@ -330,7 +335,9 @@ RT_DEV void scan_list_deferred(const float4* __restrict__ tab, const uint32_t* _
 // fall back to resolving every group (rare; still exact).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr uint32_t kMfmaSlots = 14;                                    // entries per (ray, half) sub-list
-constexpr uint32_t kWaveCandBytes = 64 * 2 * kMfmaSlots * 2 + 128 * 2;  // lists + counts = 3840 B per wave
+constexpr uint32_t kStackSlots = 24;                                    // per-lane descent stack (tree scan): 3 * levels + 1 needed
+constexpr uint32_t kWaveListBytes = 64 * 2 * kMfmaSlots * 2 + 128 * 2;  // lists + counts = 3840 B per wave
+constexpr uint32_t kWaveCandBytes = kWaveListBytes + 64 * kStackSlots * 2;  // + stack = 6912 B per wave
 constexpr float kMarginRel = 2048.f * 5.9604645e-8f;                   // K * eps, K = 2048 (host uses the same K)
 
 // Group operand image for the filter, built once per workgroup: ops[tile][4][64] floats.
@@ -340,7 +347,7 @@ RT_DEV void build_mfma_operands(const float4* __restrict__ bounds, uint32_t nGro
         const uint32_t t = e >> 6, l = e & 63, h = l >> 5;
         const uint32_t gi = t * 32 + (l & 31);
         float4 B = make_float4(0.f, 0.f, 0.f, 1e30f);  // padding rows: a*cc~ = +huge => F < 0, never recorded
-        if (gi < nGroups) B = bounds[gi];
+        if (gi < nGroups) B = bounds[gi];  // bounds = the TOP level of the tree
         float* o = ops + (size_t)t * 256 + l;
         o[0] = h == 0 ? -B.x : -B.y;
         o[64] = h == 0 ? -B.z : 1.f;
@@ -380,9 +387,10 @@ RT_DEV void mfma_post(const f32x16& Tb, const f32x16& Tg, float cray, float bthr
     }
 }
 
+template <bool kTree>
 RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __restrict__ orig, const float* __restrict__ ops, uint32_t nTiles,
-                           uint32_t nGroups, float boundNorm, V3 o, V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand,
-                           uint32_t lane, unsigned long long* dbg) {
+                           uint32_t nTop, const float4* __restrict__ tree, const uint32_t* levelOff, uint32_t nLevels, float boundNorm, V3 o,
+                           V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand, uint32_t lane, unsigned long long* dbg) {
     const float a = dot3(d, d);
     tmin = __builtin_inff();
     idx = -1;
@@ -430,21 +438,72 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __res
         mfma_post(Tb1, Tg1, cr1, bt1, list1, cnt1, rowBase);
     }
     RT_STAMP(tf1);
-    // publish the producers' counts, then every lane resolves its OWN ray's two sub-lists
+    // publish the producers' counts, then every lane works on its OWN ray's two sub-lists
     counts[col * 2u + half] = (uint16_t)(cnt0 < 0xffffu ? cnt0 : 0xffffu);
     counts[(col + 32u) * 2u + half] = (uint16_t)(cnt1 < 0xffffu ? cnt1 : 0xffffu);
     uint32_t c0 = counts[lane * 2u], c1 = counts[lane * 2u + 1u];
     const bool overflow = c0 > kMfmaSlots || c1 > kMfmaSlots;
-    if (overflow) {  // exhaustive (still exact) fallback for this ray
-        c0 = nGroups;
+    if (overflow) {  // exhaustive (still exact) fallback for this ray: every top-level node
+        c0 = nTop;
         c1 = 0;
     }
     const uint32_t tot = c0 + c1;
     const uint16_t* mine = lists + lane * 2u * kMfmaSlots;
-    for (uint32_t it = 0; __ballot(it < tot) != 0ull; ++it) {
-        if (it < tot) {
-            const uint32_t gid = overflow ? it : (it < c0 ? mine[it] : mine[kMfmaSlots + (it - c0)]);
-            resolve_group(tab, orig, 4u * gid, o, d, a, tmin, idx);
+    if (!kTree) {
+        // flat: the top level IS the groups
+        for (uint32_t it = 0; __ballot(it < tot) != 0ull; ++it) {
+            if (it < tot) {
+                const uint32_t gid = overflow ? it : (it < c0 ? mine[it] : mine[kMfmaSlots + (it - c0)]);
+                resolve_group(tab, orig, 4u * gid, o, d, a, tmin, idx);
+            }
+        }
+    } else {
+        // descent: per-lane depth-first walk of the 4-ary bounds hierarchy below each surviving top node.  A node id
+        // is level << 13 | index.  Internal steps run while ANY lane has an internal node on top of its stack; exact
+        // leaf steps run when every live lane is at a leaf, so both kinds of step run with many lanes.
+        uint16_t* stack = waveCand + kWaveListBytes / 2 + lane;  // [slot][lane]
+        const uint32_t topLevel = nLevels - 1u;
+        uint32_t sp = 0, nextTop = 0;
+        for (;;) {
+            if (sp == 0 && nextTop < tot) {
+                const uint32_t t = overflow ? nextTop : (nextTop < c0 ? mine[nextTop] : mine[kMfmaSlots + (nextTop - c0)]);
+                ++nextTop;
+                stack[0] = (uint16_t)((topLevel << 13) | t);
+                sp = 1;
+            }
+            const bool has = sp > 0;
+            if (__ballot(has) == 0ull) break;
+            const uint32_t node = has ? stack[(sp - 1u) * kWaveSize] : 0u;
+            const uint32_t lvl = node >> 13, j = node & 0x1fffu;
+            const bool internal = has && lvl > 0u;
+            if (__ballot(internal) != 0ull) {
+                if (internal) {
+                    --sp;
+                    const uint32_t cl = lvl - 1u;
+                    uint32_t off = levelOff[0];
+#pragma unroll
+                    for (uint32_t k = 1; k < kMaxLevels - 1; ++k) off = cl == k ? levelOff[k] : off;
+                    const float4* ch = tree + off + 4u * j;
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) {
+                        const float4 B = ch[q];
+                        const float dC = __builtin_fmaf(d.z, B.z, __builtin_fmaf(d.y, B.y, d.x * B.x));
+                        const float oC = __builtin_fmaf(o.z, B.z, __builtin_fmaf(o.y, B.y, o.x * B.x));
+                        const float b = dO - dC;
+                        const float t = cr + __builtin_fmaf(m2a, oC, a * B.w);
+                        const float f = __builtin_fmaf(b, b, -t);
+                        const float u = bt - b;
+                        const int rej = __float_as_int(f) | (__float_as_int(u) & ~__float_as_int(t));
+                        if (rej >= 0) {
+                            stack[sp * kWaveSize] = (uint16_t)((cl << 13) | (4u * j + q));
+                            ++sp;
+                        }
+                    }
+                }
+            } else if (has) {
+                --sp;
+                resolve_group(tab, orig, 4u * j, o, d, a, tmin, idx);
+            }
         }
     }
 #ifdef RT_STAMPS
@@ -619,8 +678,11 @@ enum : uint32_t { kIdle = 0u, kNeedClosest = 1u, kNeedShadow = 2u };
 // never synchronise with each other after the LDS staging barrier, and every wave's loop ends when
 // the (bounded, monotonically consumed) queue is exhausted and its at most 64 paths of at most
 // max_depth+1 segments have finished.
-template <bool kLds, int kThreads, bool kMfma>
+// kScan: 0 = VALU sign filter per group (any scene size), 1 = matrix-core filter over the groups (tables in LDS),
+// 2 = matrix-core filter over the top level of the bounds hierarchy + per-lane descent (tables through L2).
+template <bool kLds, int kThreads, int kScan>
 __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p) {
+    constexpr bool kMfma = kScan != 0;
     extern __shared__ float4 smem[];
     const float4* scanTab = p.scan;
     const uint32_t* origTab = p.orig;
@@ -628,9 +690,12 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
     const rt_material* matTab = p.mats;
     // per-wave candidate regions first (kWaveCandBytes each; the VALU scan uses the first 2 KiB of its region)
     uint16_t* candBase = reinterpret_cast<uint16_t*>(smem);
-    float4* tabBase = smem + (kThreads / kWaveSize) * (kWaveCandBytes / 16);
+    constexpr uint32_t kWaveRegion = kScan == 2 ? kWaveCandBytes : kWaveListBytes;  // the descent stack only exists in tree mode
+    float4* tabBase = smem + (kThreads / kWaveSize) * (kWaveRegion / 16);
     const float* mfmaOps = nullptr;
-    const uint32_t nTiles = (p.n_groups + 31u) / 32u;
+    const uint32_t topLevel = p.n_levels - 1u;
+    const uint32_t nTop = p.level_cnt[topLevel];
+    const uint32_t nTiles = (nTop + 31u) / 32u;
     if (kLds) {
         // LDS image (16-byte aligned pieces): scan | orig | materials (48 B = 3 float4) | radii | filter operands
         float4* ldsScan = tabBase;
@@ -646,7 +711,7 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
         for (uint32_t k = threadIdx.x; k < p.n; k += blockDim.x) ldsRad[k] = p.radius[k];
         if (kMfma) {
             float* ldsOps = ldsRad + ((p.n + 3u) & ~3u);
-            build_mfma_operands(p.bounds, p.n_groups, nTiles, ldsOps, threadIdx.x, blockDim.x);
+            build_mfma_operands(p.tree + p.level_off[topLevel], nTop, nTiles, ldsOps, threadIdx.x, blockDim.x);
             mfmaOps = ldsOps;
         }
         __syncthreads();
@@ -654,10 +719,16 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
         origTab = ldsOrig;
         radTab = ldsRad;
         matTab = reinterpret_cast<const rt_material*>(ldsMat);
+    } else if (kMfma) {
+        // tables stay in global memory; only the top level's operand image lives in LDS
+        float* ldsOps = reinterpret_cast<float*>(tabBase);
+        build_mfma_operands(p.tree + p.level_off[topLevel], nTop, nTiles, ldsOps, threadIdx.x, blockDim.x);
+        mfmaOps = ldsOps;
+        __syncthreads();
     }
 
     const uint32_t lane = threadIdx.x & (kWaveSize - 1);
-    uint16_t* waveCand = candBase + (threadIdx.x / kWaveSize) * (kWaveCandBytes / 2);
+    uint16_t* waveCand = candBase + (threadIdx.x / kWaveSize) * (kWaveRegion / 2);
     uint16_t* cand = waveCand + lane;
     const V3 sunDir = v3(p.sun_dir[0], p.sun_dir[1], p.sun_dir[2]);
 
@@ -732,7 +803,8 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
         if (kMfma) {
             // every lane takes part: lane l also supplies operands for, and filters half the spheres of,
             // the ray owned by lane l^32, whether or not its own ray is live
-            scan_list_mfma(scanTab, origTab, mfmaOps, nTiles, p.n_groups, p.bound_norm, ro, rd, state != kIdle, tmin, idx, waveCand, lane, dbgScan);
+            scan_list_mfma<kScan == 2>(scanTab, origTab, mfmaOps, nTiles, nTop, p.tree, p.level_off, p.n_levels, p.bound_norm, ro, rd,
+                                       state != kIdle, tmin, idx, waveCand, lane, dbgScan);
         } else if (state != kIdle) {
             scan_list_deferred(scanTab, origTab, p.n_padded, ro, rd, tmin, idx, cand);
         }

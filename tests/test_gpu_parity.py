@@ -224,8 +224,8 @@ def test_image_parity_with_oracle(hip, oracle, scenes_mod, name, W, H, s1, depth
     assert sg.traversals == so.traversals and sg.segments == so.segments and sg.samples == so.samples
 
 
-def test_grid10k_scene_streams_from_global_memory(hip, oracle, scenes_mod):
-    # C5 geometry: 10,004 spheres do not fit the LDS image; the kernel scans the list through L2
+def test_grid10k_scene_descends_the_bounds_hierarchy(hip, oracle, scenes_mod):
+    # C5 geometry: 10,004 spheres -> 2,504 groups -> 4 levels of bounds; tables stay in global memory (L2)
     sc = scenes_mod.build_scene("grid10k", 1, 64, 64)
     assert sc.n == 10004
     hip.upload(sc)
@@ -237,6 +237,17 @@ def test_grid10k_scene_streams_from_global_memory(hip, oracle, scenes_mod):
     ho, _ = orc.download()
     assert_same(hg, ho, "grid10k HDR")
     assert sg.traversals == so.traversals
+    # C5's own aspect and a grazing view over the whole field (many candidate nodes per ray)
+    n = 1500
+    rng = np.random.default_rng(8)
+    ijs = np.stack([rng.integers(0, 4096, n), rng.integers(0, 4096, n), rng.integers(1, 65, n)], 1).astype(np.uint32)
+    sc2 = scenes_mod.build_scene("grid10k", 1, 4096, 4096)
+    hip.upload(sc2)
+    orc.upload(sc2)
+    rg, tg = hip.unit_trace(4096, 4096, ijs, 50, 1)
+    ro, to = orc.trace(4096, 4096, ijs, 50, 1, accel=oracle.ACCEL_BVH)
+    assert_same(rg, ro, "C5 per-sample radiance")
+    assert np.array_equal(tg, to)
 
 
 def test_forced_global_tables_equal_lds_tables(hip, scenes_mod, monkeypatch):
@@ -302,6 +313,25 @@ def test_matrix_core_scan_equals_valu_scan(hip, scenes_mod, monkeypatch):
     r2.close()
     assert_same(a, b, "matrix-core scan vs VALU scan")
     assert sa.traversals == sb.traversals
+
+
+def test_bounds_hierarchy_descent_equals_flat_filter(hip, scenes_mod, monkeypatch):
+    """RT_TREE_TOP=16 forces a three-level bounds hierarchy (matrix-core filter on 8 top nodes, per-lane descent
+    below, tables through L2) on the cover scene; the default is the flat filter over all 126 groups."""
+    from cpuraytracer_amd import HipRenderer
+    sc = scenes_mod.build_scene("cover", 1, 160, 104)
+    hip.upload(sc)
+    sa = hip.render(160, 104, 1, 5, 50, 1)
+    a, _ = hip.download(ldr=False)
+    for top in ("16", "32"):
+        monkeypatch.setenv("RT_TREE_TOP", top)
+        r2 = HipRenderer(0)
+        r2.upload(sc)
+        sb = r2.render(160, 104, 1, 5, 50, 1)
+        b, _ = r2.download(ldr=False)
+        r2.close()
+        assert_same(a, b, "hierarchy descent (top <= %s) vs flat filter" % top)
+        assert sa.traversals == sb.traversals
 
 
 def test_candidate_list_overflow_falls_back_exactly(hip, oracle):
