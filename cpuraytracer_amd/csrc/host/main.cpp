@@ -6,17 +6,18 @@
 #include <cstring>
 #include <string>
 
+#include "multi_gpu.h"
 #include "spheres-app.h"
 
 static void Usage() {
     std::puts("usage: spheres [--width N] [--height N] [--spp N] [--frame-spp N] [--depth N] [--fov F] [--aperture F]\n"
-              "               [--scene cover|three|grid10k] [--scene-seed N] [--seed N] [--device N] [--out file.ppm] [--quiet]");
+              "               [--scene cover|three|grid10k] [--scene-seed N] [--seed N] [--device N] [--gpus N] [--out file.ppm] [--quiet]");
 }
 
 int main(int argc, char** argv) {
     AppSettingsT st;
     uint32_t spp = 16;
-    int device = 0;
+    int device = 0, gpus = 0;
     std::string out = "out.ppm";
     bool quiet = false, fovSet = false, apSet = false;
     for (int a = 1; a < argc; ++a) {
@@ -36,6 +37,7 @@ int main(int argc, char** argv) {
         else if (k == "--scene-seed") st.sceneSeed = std::strtoull(val(), nullptr, 10);
         else if (k == "--seed") st.renderSeed = std::strtoull(val(), nullptr, 10);
         else if (k == "--device") device = std::atoi(val());
+        else if (k == "--gpus") gpus = std::atoi(val());
         else if (k == "--out") out = val();
         else if (k == "--quiet") quiet = true;
         else { Usage(); return k == "--help" ? 0 : 2; }
@@ -46,6 +48,26 @@ int main(int argc, char** argv) {
     }
     if (st.samplesPerFrame == 0 || spp == 0 || st.k_backbufferWidth <= 0 || st.k_backbufferHeight <= 0) { Usage(); return 2; }
     if (spp % st.samplesPerFrame != 0) st.samplesPerFrame = 1;
+    if (gpus > 0) {  // rows sharded over `gpus` devices, RCCL gather to device 0
+        MultiGpuResult res;
+        std::string err;
+        if (RenderMultiGpu(st, gpus, spp, res, &err) != 0) {
+            std::fprintf(stderr, "spheres: %s\n", err.c_str());
+            return 1;
+        }
+        FILE* f = std::fopen(out.c_str(), "wb");
+        if (!f) {
+            std::fprintf(stderr, "spheres: cannot write %s\n", out.c_str());
+            return 1;
+        }
+        std::fprintf(f, "P6\n%d %d\n255\n", st.k_backbufferWidth, st.k_backbufferHeight);
+        std::fwrite(res.ldr.data(), 1, res.ldr.size(), f);
+        std::fclose(f);
+        std::printf("{\"out\": \"%s\", \"gpus\": %d, \"spp\": %u, \"render_s\": %.4f, \"Msamples_per_s\": %.2f, \"traversals_per_sample\": %.4f}\n",
+                    out.c_str(), gpus, spp, res.renderSeconds, (double)res.samples / res.renderSeconds / 1e6,
+                    res.samples ? (double)res.traversals / (double)res.samples : 0.0);
+        return 0;
+    }
     SpheresApp app(st);
     app.SetQuiet(quiet);
     try {

@@ -486,3 +486,70 @@ def test_cli_writes_the_same_ppm(hip, oracle, scenes_mod, tmp_path):
     assert data.startswith(b"P6\n200 100\n255\n")
     g = np.load(os.path.join(GOLDEN, "c1_three_200x100_spp1_d8.npz"))
     assert data[len(b"P6\n200 100\n255\n"):] == g["ldr"].tobytes()
+
+
+def test_cli_multi_gpu_driver_with_rccl_gather(hip, tmp_path):
+    """`spheres --gpus 1`: the single-process multi-device driver (thread per GPU, ncclGather of the padded strips to
+    device 0, host de-interleave).  One device is all this box has; the partition/gather arithmetic for G > 1 is
+    covered by the 8-shard test above and the gloo tests."""
+    import subprocess
+    from conftest import ROOT
+    out = str(tmp_path / "c1_mgpu.ppm")
+    cli = os.path.join(ROOT, "cpuraytracer_amd", "lib", "spheres")
+    p = subprocess.run([cli, "--scene", "three", "--width", "200", "--height", "100", "--spp", "1", "--depth", "8", "--gpus", "1", "--out", out],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    g = np.load(os.path.join(GOLDEN, "c1_three_200x100_spp1_d8.npz"))
+    data = open(out, "rb").read()
+    assert data[len(b"P6\n200 100\n255\n"):] == g["ldr"].tobytes()
+    p = subprocess.run([cli, "--gpus", "64", "--width", "8", "--height", "8", "--spp", "1"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 1 and "exceeds" in p.stderr
+
+
+def test_host_mirror_api(hip, oracle):
+    """Code written against the reference's class API (Camera, Sphere, BvhNode, DielectricOpaque, DirectionalLight,
+    Random::Halton*) runs against the host mirror, whose per-ray methods evaluate on the device; values == oracle."""
+    import json
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "cpuraytracer_amd", "lib", "api_selftest")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    j = json.loads(p.stdout)
+    O = oracle.lib()
+    f32 = lambda v: np.asarray(v, dtype=np.float32)
+    assert np.float32(j["halton_100_3"]) == np.float32(O.orc_halton(100, 3))
+    o2, o3 = (C.c_float * 2)(), (C.c_float * 3)()
+    O.orc_halton_disk(7, 4, 5, o2)
+    O.orc_halton_hemisphere(3, 5, 7, o3)
+    assert np.array_equal(f32(j["disk_7"]), f32(list(o2))) and np.array_equal(f32(j["hemi_3"]), f32(list(o3)))
+    # camera ray: oracle's Camera with the same constructor arguments
+    cam = oracle.RtCamera()
+    o = np.array([12, 2, -2.5]); la = np.array([0, 1, 0])
+    focal = float(np.sqrt(np.float32(np.float32(np.float32(144) + np.float32(1)) + np.float32(6.25))))
+    O.orc_camera_make((C.c_float * 3)(*o), (C.c_float * 3)(*la), 25.0, 1.5, focal, 0.4, C.byref(cam))
+    sc = oracle.build_scene("three", 1, 1.5)
+    sc.camera = cam
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    # Camera::GetRay(uv, offset) through the hit of the C1 spheres
+    ray = np.array([[0.1, 0.05, 0.0, 0, 0, 0]], dtype=np.float32)
+    d = np.array([0.05, -0.02, 1.0], dtype=np.float32)
+    n2 = np.float32(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+    ray[0, 3:] = d / np.sqrt(n2)
+    h = orc.closest_hit(ray)[0]
+    assert j["sphere_hit"] == 1 and np.float32(j["sphere_t"]) == h[0]
+    assert np.array_equal(f32(j["sphere_pos"]), h[2:5]) and np.array_equal(f32(j["sphere_normal"]), h[5:8]) and np.array_equal(f32(j["sphere_uv"]), h[8:10])
+    m = oracle.RtMaterial.from_buffer_copy(sc.materials[0].tobytes())
+    att, dr, nd, loc = (C.c_float * 3)(), (C.c_float * 3)(), C.c_uint32(), (C.c_float * 3)()
+    f = lambda a: (C.c_float * len(a))(*[float(v) for v in a])
+    scat = O.orc_unit_scatter(C.byref(m), f(ray[0, 3:]), f(h[2:5]), f(h[5:8]), f(h[8:10]), f([0.5, 0.3, 0.7]), att, dr, C.byref(nd))
+    assert j["scattered"] == scat == 1 and np.array_equal(f32(j["attenuation"]), f32(list(att))) and np.array_equal(f32(j["scatter_dir"]), f32(list(dr)))
+    O.orc_unit_emit_shade(C.byref(m), C.byref(sc.sun), (C.c_float * 3)(12.0, 2.0, -2.5), f(h[2:5]), f(h[5:8]), f(h[8:10]), loc)
+    shadow = orc.closest_hit(np.concatenate([h[2:5], f32(list(sc.sun.direction))])[None, :])[0]
+    occluded = shadow[1:2].view(np.int32)[0] >= 0  # light.cpp:13-18: an occluded sun contributes nothing
+    assert np.array_equal(f32(j["shade"]), np.zeros(3, dtype=np.float32) if occluded else f32(list(loc)))
+    assert j["scene_moved_out"] == 1 and j["bvh_hit"] == 1
+    hb = orc.closest_hit(np.array([[0.45, 1.0, 0.55, 0, -1, 0]], dtype=np.float32))[0]
+    assert np.float32(j["bvh_t"]) == hb[0] and np.array_equal(f32(j["bvh_normal"]), hb[5:8])
+    assert j["shade_in_shadow"] == [0.0, 0.0, 0.0]
