@@ -95,6 +95,7 @@ struct rt_ctx {
     uint32_t blocksPerCu = 4;
     uint32_t blockThreads = 256;
     bool useMfma = true;  // matrix-core pre-filter for the list scan (RT_SCAN=valu disables)
+    bool matsInLds = true;   // RT_MATS_LDS=0 leaves the material table in global memory (frees 48 B/sphere of LDS)
     uint32_t treeTop = 128;  // largest top level the matrix-core filter takes (4 tiles of 32); RT_TREE_TOP overrides
     bool forceGlobal = false;
 };
@@ -235,13 +236,16 @@ static void BuildLayout(const rt_sphere* sp, uint32_t n, uint32_t topMax, SceneL
         members.swap(up);
     }
 }
-static size_t LdsBytesFor(uint32_t n, uint32_t nPadded) { return (size_t)nPadded * (16 + 4) + (size_t)n * 48 + (size_t)((n + 3) / 4) * 16; }
+static size_t LdsBytesFor(uint32_t n, uint32_t nPadded, bool mats) {
+    return (size_t)nPadded * (16 + 4) + (mats ? (size_t)n * 48 : 0) + (size_t)((n + 3) / 4) * 16;
+}
 static size_t MfmaOpsBytesFor(uint32_t nGroups) { return (size_t)((nGroups + 31u) / 32u) * 4 * 64 * 4; }
 
 // Launch the megakernel over total paths described by tp.
 static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     RT_HIP(hipMemsetAsync(ctx->queue.ptr, 0, sizeof(uint32_t), ctx->stream));
-    const size_t lds = LdsBytesFor(tp.n, tp.n_padded);
+    tp.mats_in_lds = ctx->matsInLds ? 1u : 0u;
+    const size_t lds = LdsBytesFor(tp.n, tp.n_padded, ctx->matsInLds);
     const bool useLds = !ctx->forceGlobal && lds <= 48 * 1024 && tp.n_padded < 65536;
     if (tp.n_padded >= 65536) return Fail(RT_ERR_INVALID_ARG, "scenes beyond 65,000 spheres are not supported by the 16-bit candidate lists");
     const uint32_t maxBlocks = (uint32_t)ctx->cuCount * ctx->blocksPerCu;
@@ -269,6 +273,7 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     do {                                                               \
         if (ctx->blockThreads == 1024) RT_LAUNCH(LDS, 1024, M);        \
         else if (ctx->blockThreads == 768) RT_LAUNCH(LDS, 768, M);     \
+        else if (ctx->blockThreads == 640) RT_LAUNCH(LDS, 640, M);     \
         else if (ctx->blockThreads == 512) RT_LAUNCH(LDS, 512, M);     \
         else if (ctx->blockThreads == 384) RT_LAUNCH(LDS, 384, M);     \
         else RT_LAUNCH(LDS, 256, M);                                   \
@@ -321,6 +326,7 @@ int rt_create(int device_ordinal, rt_ctx** out) {
     {
         const char* scan = std::getenv("RT_SCAN");
         ctx->useMfma = !(scan && std::strcmp(scan, "valu") == 0);
+        ctx->matsInLds = EnvU32("RT_MATS_LDS", 1) != 0;
         ctx->treeTop = EnvU32("RT_TREE_TOP", 128);
         if (ctx->treeTop < 4 || ctx->treeTop > 128) ctx->treeTop = 128;
     }
@@ -330,7 +336,8 @@ int rt_create(int device_ordinal, rt_ctx** out) {
     if (ctx->blocksPerCu == 0) ctx->blocksPerCu = 1;
     ctx->forceGlobal = EnvU32("RT_FORCE_GLOBAL_TABLES", 0) != 0;
     ctx->blockThreads = EnvU32("RT_BLOCK_THREADS", ctx->useMfma ? 1024 : 256);
-    if (ctx->blockThreads != 256 && ctx->blockThreads != 384 && ctx->blockThreads != 512 && ctx->blockThreads != 768 &&
+    if (ctx->blockThreads != 256 && ctx->blockThreads != 384 && ctx->blockThreads != 512 && ctx->blockThreads != 640 &&
+        ctx->blockThreads != 768 &&
         ctx->blockThreads != 1024)
         ctx->blockThreads = 256;
     int rc = ctx->queue.Reserve(1);

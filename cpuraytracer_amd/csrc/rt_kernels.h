@@ -76,6 +76,7 @@ struct TraceParams {
     const rt_material* mats;   // [n] by original index
     uint32_t n;                // real spheres
     uint32_t n_groups;         // groups of four entries (even)
+    uint32_t mats_in_lds;      // stage the material table into LDS (else it is read through L2)
     float bound_norm;          // max over groups of |C| + R (scale of the filter's behind-the-origin threshold)
     uint32_t n_padded;         // 4 * n_groups + 4
     float cam_o[3], cam_x[3], cam_y[3], cam_oip[3];
@@ -334,7 +335,7 @@ RT_DEV void scan_list_deferred(const float4* __restrict__ tab, const uint32_t* _
 // with its own sub-list and register counter (no atomics).  A sub-list that overflows makes its ray
 // fall back to resolving every group (rare; still exact).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr uint32_t kMfmaSlots = 14;                                    // entries per (ray, half) sub-list
+constexpr uint32_t kMfmaSlots = 10;                                    // entries per (ray, half) sub-list
 constexpr uint32_t kStackSlots = 24;                                    // per-lane descent stack (tree scan): 3 * levels + 1 needed
 constexpr uint32_t kWaveListBytes = 64 * 2 * kMfmaSlots * 2 + 128 * 2;  // lists + counts = 3840 B per wave
 constexpr uint32_t kWaveCandBytes = kWaveListBytes + 64 * kStackSlots * 2;  // + stack = 6912 B per wave
@@ -425,17 +426,21 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __res
         const float* op = ops + (size_t)s * 256 + lane;
         const float ab1 = op[0], ab2 = op[64], ag1 = op[128], ag2 = op[192];
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        f32x16 Tb0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab1, bb00, zero, 0, 0, 0);
-        f32x16 Tg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag1, bg00, zero, 0, 0, 0);
-        f32x16 Tb1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab1, bb10, zero, 0, 0, 0);
-        f32x16 Tg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag1, bg10, zero, 0, 0, 0);
-        Tb0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab2, bb01, Tb0, 0, 0, 0);
-        Tg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag2, bg01, Tg0, 0, 0, 0);
-        Tb1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab2, bb11, Tb1, 0, 0, 0);
-        Tg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ag2, bg11, Tg1, 0, 0, 0);
         const uint32_t rowBase = 32u * s + 4u * half;
-        mfma_post(Tb0, Tg0, cr0, bt0, list0, cnt0, rowBase);
-        mfma_post(Tb1, Tg1, cr1, bt1, list1, cnt1, rowBase);
+        {   // ray tile 0 (rays 0..31)
+            f32x16 Tb = __builtin_amdgcn_mfma_f32_32x32x2f32(ab1, bb00, zero, 0, 0, 0);
+            f32x16 Tg = __builtin_amdgcn_mfma_f32_32x32x2f32(ag1, bg00, zero, 0, 0, 0);
+            Tb = __builtin_amdgcn_mfma_f32_32x32x2f32(ab2, bb01, Tb, 0, 0, 0);
+            Tg = __builtin_amdgcn_mfma_f32_32x32x2f32(ag2, bg01, Tg, 0, 0, 0);
+            mfma_post(Tb, Tg, cr0, bt0, list0, cnt0, rowBase);
+        }
+        {   // ray tile 1 (rays 32..63)
+            f32x16 Tb = __builtin_amdgcn_mfma_f32_32x32x2f32(ab1, bb10, zero, 0, 0, 0);
+            f32x16 Tg = __builtin_amdgcn_mfma_f32_32x32x2f32(ag1, bg10, zero, 0, 0, 0);
+            Tb = __builtin_amdgcn_mfma_f32_32x32x2f32(ab2, bb11, Tb, 0, 0, 0);
+            Tg = __builtin_amdgcn_mfma_f32_32x32x2f32(ag2, bg11, Tg, 0, 0, 0);
+            mfma_post(Tb, Tg, cr1, bt1, list1, cnt1, rowBase);
+        }
     }
     RT_STAMP(tf1);
     // publish the producers' counts, then every lane works on its OWN ray's two sub-lists
@@ -565,10 +570,11 @@ struct ScriptedDraws {
 // ------------------------------------------------- hit processing (A8, A10-A13, A15)
 // Runs Material::Scatter (draws first, material.cpp) then DirectionalLight::Shade's unoccluded
 // value (light.cpp:21-40).  Outputs: scattered flag, attenuation, scattered direction, local =
-// Emit + Shade assuming the sun is visible (the caller adds it only if the shadow scan misses).
+// Emit + Shade with the sun visible and localOccluded = Emit + 0 (the caller adds one of the two once the
+// shadow scan has decided; Emit is non-zero only for Emissive spheres, which never scatter).
 template <class Draws>
 RT_DEV bool scatter_and_shade(const TraceParams& p, const Mat& m, V3 rd, V3 pos, V3 nrm, Draws& draws, V3& atten, V3& outDir,
-                              V3& local) {
+                              V3& local, V3& localOccluded) {
     const float uvx = 0.5f * nrm.x + 0.5f;  // Sphere::ComputeUV, ray-tracing.cpp:26-40
     const float uvy = 0.5f * nrm.z + 0.5f;
     const V3 tex = eval_texture(m, uvx, uvy);
@@ -660,6 +666,7 @@ RT_DEV bool scatter_and_shade(const TraceParams& p, const Mat& m, V3 rd, V3 pos,
     V3 emit = v3(0.f, 0.f, 0.f);
     if (m.type == RT_MAT_EMISSIVE) emit = m.luminance * tex;
     local = emit + shade;
+    localOccluded = emit + v3(0.f, 0.f, 0.f);  // Shade returns XM_Zero when the sun is occluded (light.cpp:15-18)
     return scattered;
 }
 
@@ -681,7 +688,7 @@ enum : uint32_t { kIdle = 0u, kNeedClosest = 1u, kNeedShadow = 2u };
 // kScan: 0 = VALU sign filter per group (any scene size), 1 = matrix-core filter over the groups (tables in LDS),
 // 2 = matrix-core filter over the top level of the bounds hierarchy + per-lane descent (tables through L2).
 template <bool kLds, int kThreads, int kScan>
-__global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p) {
+__global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_kernel(const TraceParams p) {
     constexpr bool kMfma = kScan != 0;
     extern __shared__ float4 smem[];
     const float4* scanTab = p.scan;
@@ -701,13 +708,14 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
         float4* ldsScan = tabBase;
         uint32_t* ldsOrig = reinterpret_cast<uint32_t*>(ldsScan + p.n_padded);
         float4* ldsMat = reinterpret_cast<float4*>(ldsOrig + p.n_padded);  // n_padded is a multiple of 4
-        float* ldsRad = reinterpret_cast<float*>(ldsMat + (size_t)p.n * 3);
+        const uint32_t nMatLds = p.mats_in_lds ? p.n : 0u;
+        float* ldsRad = reinterpret_cast<float*>(ldsMat + (size_t)nMatLds * 3);
         const float4* gMat = reinterpret_cast<const float4*>(p.mats);
         for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) {
             ldsScan[k] = p.scan[k];
             ldsOrig[k] = p.orig[k];
         }
-        for (uint32_t k = threadIdx.x; k < p.n * 3; k += blockDim.x) ldsMat[k] = gMat[k];
+        for (uint32_t k = threadIdx.x; k < nMatLds * 3; k += blockDim.x) ldsMat[k] = gMat[k];
         for (uint32_t k = threadIdx.x; k < p.n; k += blockDim.x) ldsRad[k] = p.radius[k];
         if (kMfma) {
             float* ldsOps = ldsRad + ((p.n + 3u) & ~3u);
@@ -718,7 +726,7 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
         scanTab = ldsScan;
         origTab = ldsOrig;
         radTab = ldsRad;
-        matTab = reinterpret_cast<const rt_material*>(ldsMat);
+        if (p.mats_in_lds) matTab = reinterpret_cast<const rt_material*>(ldsMat);
     } else if (kMfma) {
         // tables stay in global memory; only the top level's operand image lives in LDS
         float* ldsOps = reinterpret_cast<float*>(tabBase);
@@ -738,7 +746,7 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
     V3 pend = v3(0.f, 0.f, 0.f), nextDir = v3(0.f, 0.f, 0.f);
     StreamDraws draws{Rng{1u, 0u, 0u, 0u}};
     uint32_t q = 0, depth = 0, state = kIdle, pathTrav = 0;
-    bool contAfterShadow = false;
+    bool contAfterShadow = false, pathScattered = false;
     uint32_t nTrav = 0, nSeg = 0;
 
     // wave-uniform queue window
@@ -831,9 +839,13 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
                 const V3 center = v3(S.x, S.y, S.z);
                 const V3 pos = tmin * rd + ro;          // XMVectorMultiplyAdd(t, dir, origin), ray-tracing.cpp:57
                 const V3 nrm = (pos - center) / radius;  // ray-tracing.cpp:58
-                V3 atten, local;
-                const bool scattered = scatter_and_shade(p, m, rd, pos, nrm, draws, atten, nextDir, local);
+                V3 atten, local, localOcc;
+                const bool scattered = scatter_and_shade(p, m, rd, pos, nrm, draws, atten, nextDir, local, localOcc);
                 pend = thr * local;
+                // a path that does not scatter ends here, so its nextDir registers carry throughput * (Emit + 0),
+                // the value the reference adds when the sun is occluded (0 for every non-emissive material)
+                pathScattered = scattered;
+                if (!scattered) nextDir = thr * localOcc;
                 contAfterShadow = (depth < p.max_depth) && scattered;  // spheres-app.cpp:247
                 thr = thr * atten;
                 ro = pos;  // shadow ray and scattered ray both start at hit.pos
@@ -841,7 +853,8 @@ __global__ void __launch_bounds__(kThreads) rt_trace_kernel(const TraceParams p)
                 state = kNeedShadow;
             }
         } else if (state == kNeedShadow) {
-            if (idx < 0) rad = rad + pend;  // sun visible: radiance += throughput * (Emit + Shade)
+            if (idx < 0) rad = rad + pend;              // sun visible: radiance += throughput * (Emit + Shade)
+            else if (!pathScattered) rad = rad + nextDir;  // occluded: radiance += throughput * (Emit + 0)
             if (contAfterShadow) {
                 rd = nextDir;
                 ++depth;
@@ -1019,8 +1032,8 @@ __global__ void k_unit_scatter(const TraceParams p, const rt_material* mat, cons
     const float* q = in + 12 * (size_t)k;
     const Mat m = load_material(mat, 0);
     ScriptedDraws draws{{q[9], q[10], q[11]}, 0u};
-    V3 atten, dir, local;
-    const bool sc = scatter_and_shade(p, m, v3(q[0], q[1], q[2]), v3(q[3], q[4], q[5]), v3(q[6], q[7], q[8]), draws, atten, dir, local);
+    V3 atten, dir, local, localOcc;
+    const bool sc = scatter_and_shade(p, m, v3(q[0], q[1], q[2]), v3(q[3], q[4], q[5]), v3(q[6], q[7], q[8]), draws, atten, dir, local, localOcc);
     float* w = out + 11 * (size_t)k;
     w[0] = sc ? 1.f : 0.f;
     w[1] = atten.x; w[2] = atten.y; w[3] = atten.z;

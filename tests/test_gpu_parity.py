@@ -368,6 +368,47 @@ def test_filter_margins_hold_far_from_the_origin_and_at_odd_scales(hip, oracle, 
     _assert_image_equals_oracle(hip, oracle, sc, 120, 80, 2, 20)
 
 
+@pytest.mark.parametrize("seed,n", [(1, 5), (2, 37), (3, 130), (4, 511), (5, 513), (6, 700), (7, 2300), (8, 64), (9, 300), (10, 1200)])
+def test_random_scenes_differential(hip, oracle, seed, n):
+    """Differential fuzzing: random sphere soups (sizes over three decades, overlapping spheres, every material and
+    texture kind, emissive spheres, random cameras with and without depth of field) — per-sample radiance, traversal
+    counts and closest hits must equal the oracle's bit for bit.  n <= 512 runs the flat matrix-core filter, larger
+    scenes the bounds hierarchy."""
+    rng = np.random.default_rng(1000 + seed)
+    extent = rng.choice([3.0, 12.0, 60.0])
+    centers = rng.uniform(-extent, extent, size=(n, 3))
+    centers[:, 1] = np.abs(centers[:, 1]) * 0.25
+    radii = np.exp(rng.uniform(np.log(0.02), np.log(1.5), n)) * extent / 12.0
+    if seed % 2 == 0:  # a huge floor like the cover scene's
+        centers = np.concatenate([centers, [[0.0, -400.0 - radii.max(), 0.0]]])
+        radii = np.concatenate([radii, [400.0]])
+    n = len(radii)
+    types = rng.choice([0, 0, 0, 1, 2, 3], n).astype(np.uint32)
+    sc = _custom_scene(oracle, centers.astype(np.float32), radii.astype(np.float32), types, rng.uniform(-1, 1, 3) * extent * 1.2 + [0, extent * 0.4, 0],
+                       rng.uniform(-0.3, 0.3, 3) * extent, float(rng.uniform(20, 70)), 1.5, aperture=float(rng.choice([0.0, 0.3, 2.0])))
+    k255 = np.float32(1) / np.float32(255)
+    sc.materials["tex_type"] = rng.integers(0, 2, n)
+    sc.materials["tiling"] = rng.choice([4.0, 50.0, 2500.0], n)
+    sc.materials["rgb0"] = rng.integers(0, 256, (n, 3)).astype(np.float32) * k255
+    sc.materials["rgb1"] = rng.integers(0, 256, (n, 3)).astype(np.float32) * k255
+    sc.materials["smoothness"] = np.where(types == 1, 0.0, rng.uniform(1.0, 64.0, n)).astype(np.float32)
+    sc.materials["ior"] = rng.uniform(1.1, 2.4, n).astype(np.float32)
+    sc.materials["luminance"] = np.where(types == 3, rng.uniform(100.0, 20000.0, n), 0.0).astype(np.float32)
+    hip.upload(sc)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    W, H, m = 300, 200, 3000
+    ijs = np.stack([rng.integers(0, W, m), rng.integers(0, H, m), rng.integers(1, 600, m)], 1).astype(np.uint32)
+    rays = orc.primary_rays(W, H, ijs)
+    assert_same(hip.unit_primary_rays(W, H, ijs), rays, "primary rays")
+    assert_same(hip.unit_closest_hit(rays), orc.closest_hit(rays, oracle.ACCEL_BVH), "closest hits")
+    rg, tg = hip.unit_trace(W, H, ijs, 30, 77 + seed)
+    ro, to = orc.trace(W, H, ijs, 30, 77 + seed, accel=oracle.ACCEL_BVH)
+    assert_same(rg, ro, "per-sample radiance")
+    assert np.array_equal(tg, to)
+    assert np.isfinite(rg).all()
+
+
 # ------------------------------------------- properties at BASELINE.json's full size (C2)
 @pytest.fixture(scope="module")
 def c2_full(hip, scenes_mod):
