@@ -81,12 +81,21 @@ def main():
     N = args.gpus
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    # RT_BENCH_REHEARSAL=1: run the N-rank code path on fewer devices than ranks (ranks share GPUs, gloo instead
+    # of RCCL, strips gathered through host memory).  For checking the distributed plumbing on a 1-GPU box only;
+    # its numbers mean nothing and the JSON line says so.
+    rehearsal = os.environ.get("RT_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if N > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=N)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as g
     if rank == 0:
@@ -114,8 +123,13 @@ def main():
         st = r.render(W_IMG, H_IMG, 1, 1 + spp, DEPTH, RENDER_SEED, rowset=rs)
         r.resolve()
         r.copy_to_device(hdr_strip.data_ptr(), ldr_strip.data_ptr())
-        parts_h = D.gather_strip(hdr_strip, H_IMG, rank, N)  # RCCL gather of tile rows (no-op at N = 1)
-        parts_l = D.gather_strip(ldr_strip, H_IMG, rank, N)
+        if rehearsal:
+            r.synchronize()
+            parts_h = D.gather_strip(hdr_strip.cpu(), H_IMG, rank, N)
+            parts_l = D.gather_strip(ldr_strip.cpu(), H_IMG, rank, N)
+        else:
+            parts_h = D.gather_strip(hdr_strip, H_IMG, rank, N)  # RCCL gather of tile rows (no-op at N = 1)
+            parts_l = D.gather_strip(ldr_strip, H_IMG, rank, N)
         last = (st, parts_h, parts_l)
         return st
 
@@ -135,7 +149,7 @@ def main():
         trav.append(st.traversals)
     sync()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -166,7 +180,7 @@ def main():
             "metric": "Msamples/sec (WxHxspp/s), 1200x800 cover scene spp=128 d=50",
             "value": value, "unit": "Msamples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share GPUs over gloo, not a measurement)" if rehearsal else ""),
             "config": {"workload": "RTIOW cover scene (%d spheres, scene seed %d) %dx%d spp=%d depth=%d, render seed %d; "
                                    "rows sharded cyclically over %d GPU(s) in 4-row blocks, RCCL gather of strips to rank 0"
                                    % (n_spheres, SCENE_SEED, W_IMG, H_IMG, spp, DEPTH, RENDER_SEED, N),
