@@ -476,6 +476,63 @@ def test_c2_full_size_sharded_and_progressive_and_multipass_identity(hip, c2_ful
     assert_same(hip.download(ldr=False)[0], hdr, "multi-pass render")
 
 
+def test_c3_full_size_eight_shards_equal_one_shot(hip, scenes_mod):
+    """BASELINE config 3 on one device: 1200x800, spp 1024, rows in 8 cyclic shards (what each of 8 GPUs renders)
+    versus the one-shot render, whose 11.8 GB of samples exceed the 8 GiB workspace (two sample-range passes)."""
+    from cpuraytracer_amd import cyclic_rows, distributed as D
+    hip.upload(scenes_mod.build_scene("cover", 1, 1200, 800))
+    st = hip.render(1200, 800, 1, 1025, 50, 1)
+    assert st.samples == 1200 * 800 * 1024 and st.passes == 2
+    hip.resolve()
+    hdr, ldr = hip.download()
+    parts_h, parts_l, trav = [], [], 0
+    for rank in range(8):
+        s = hip.render(1200, 800, 1, 1025, 50, 1, rowset=cyclic_rows(800, rank, 8))
+        assert s.passes == 1 and s.local_rows == 100
+        hip.resolve()
+        h, l = hip.download()
+        parts_h.append(h)
+        parts_l.append(l)
+        trav += s.traversals
+    assert trav == st.traversals
+    assert_same(D.assemble(parts_h, 800, 8), hdr, "C3 HDR: 8 shards vs one shot")
+    assert_same(D.assemble(parts_l, 800, 8), ldr, "C3 LDR: 8 shards vs one shot")
+
+
+def test_c4_full_size_depth_of_field(hip, oracle, scenes_mod):
+    """BASELINE config 4: 1920x1080, spp 512, aperture 2.0 (divergent lens sampling).  Full-size properties +
+    spot checks against the oracle (per-sample vectors, whole-pixel sums in the reference's order)."""
+    sc = scenes_mod.build_scene("cover", 1, 1920, 1080, aperture=2.0)
+    hip.upload(sc)
+    st = hip.render(1920, 1080, 1, 513, 50, 1)
+    assert st.samples == 1920 * 1080 * 512
+    hip.resolve()
+    hdr, ldr = hip.download()
+    assert np.isfinite(hdr).all() and (hdr >= 0).all()
+    st2 = hip.render(1920, 1080, 1, 513, 50, 1)
+    assert st2.traversals == st.traversals
+    assert_same(hip.download(ldr=False)[0], hdr, "C4 second launch")
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    rng = np.random.default_rng(44)
+    n = 1200
+    ijs = np.stack([rng.integers(0, 1920, n), rng.integers(0, 1080, n), rng.integers(1, 513, n)], 1).astype(np.uint32)
+    rg, tg = hip.unit_trace(1920, 1080, ijs, 50, 1)
+    ro, to = orc.trace(1920, 1080, ijs, 50, 1, accel=oracle.ACCEL_BVH)
+    assert_same(rg, ro, "C4 per-sample radiance")
+    assert np.array_equal(tg, to)
+    out = (C.c_uint8 * 3)()
+    for i, j in ((0, 0), (1919, 1079), (960, 700), (400, 900), (1500, 650), (777, 555)):
+        pij = np.array([[i, j, s] for s in range(1, 513)], dtype=np.uint32)
+        rgb, _ = orc.trace(1920, 1080, pij, 50, 1, accel=oracle.ACCEL_BVH)
+        acc = np.zeros(3, dtype=np.float32)
+        for s in range(512):
+            acc = acc + rgb[s]
+        assert np.array_equal(acc.view(np.uint32), hdr[j, i].view(np.uint32)), (i, j)
+        oracle.lib().orc_tonemap((C.c_float * 3)(*[float(v) for v in acc]), 512, out)
+        assert list(out) == list(ldr[j, i])
+
+
 def test_seed_changes_image_and_depth_zero_is_direct_only(hip, scenes_mod):
     sc = scenes_mod.build_scene("cover", 1, 96, 64)
     hip.upload(sc)

@@ -476,3 +476,15 @@ def test_statistical_parity_with_the_reference_halton_counter_sampler(oracle):
     # and 8x8-block averages (noise / 8) agree much more tightly than single pixels
     blk = lambda x: x[:40, :56].reshape(5, 8, 7, 8, 3).mean(axis=(1, 3))
     assert np.max(np.abs(blk(ref) - blk(a))) < 8.0 * noise / 8.0 + 0.01 * blk(a).max()
+
+
+def test_oracle_runs_clean_under_sanitizers(oracle):
+    """AddressSanitizer + UBSan on the CPU build of the oracle (GPU sanitizers are unavailable):
+    scenes, both accelerators, all materials, threads and sharding run without a report, and BVH == list."""
+    import subprocess
+    from conftest import ROOT
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle_selftest_asan"], stdout=subprocess.DEVNULL)
+    p = subprocess.run([os.path.join(ROOT, "oracle", "oracle_selftest_asan")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr
