@@ -75,6 +75,8 @@ struct rt_ctx {
     uint32_t n = 0;
     DevBuf<float4> scan, tree;
     DevBuf<uint32_t> orig;
+    DevBuf<uint16_t> sgCells, sgEntries, sgGlobal;
+    bool useShadowGrid = true;  // RT_SHADOW_GRID=0 keeps every shadow ray on the scan
     DevBuf<float> radius;
     DevBuf<rt_material> mats;
     rtd::TraceParams base{};  // scene part filled at upload
@@ -236,6 +238,122 @@ static void BuildLayout(const rt_sphere* sp, uint32_t n, uint32_t topMax, SceneL
         members.swap(up);
     }
 }
+// ---------------------------------------------------------------------------------- shadow index
+// Footprints of the spheres in the plane perpendicular to the sun, binned into a uniform grid (rt_kernels.h
+// shadow_query).  Conservative by construction: footprint radius rho = sqrt(r^2 + 64 eps (2 P0^2 + 2|c|^2 + r^2))
+// (1 + 1e-4) + 1e-5 (P0 + |c| + 1) covers the reference test's own rounding for hit points with |p| <= P0 (E/a <= 16
+// eps (...), 4x safety) and the rounding of the float projection; a sphere is listed in every cell its footprint's
+// bounding square touches.
+struct ShadowGrid {
+    std::vector<uint16_t> cellStart, entries, global;
+    uint32_t nx = 0, ny = 0;
+    float e1[3] = {0, 0, 0}, e2[3] = {0, 0, 0}, u0 = 0, v0 = 0, invCell = 0, p0sq = 0;
+    bool enabled = false;
+};
+
+static void BuildShadowGrid(const rt_sphere* sp, const SceneLayout& L, const float sunDir[3], ShadowGrid& G) {
+    G = ShadowGrid{};
+    const double Lx = sunDir[0], Ly = sunDir[1], Lz = sunDir[2];
+    const double ln = std::sqrt(Lx * Lx + Ly * Ly + Lz * Lz);
+    if (!(ln > 0.5 && ln < 2.0)) return;  // not a direction: keep the scan
+    // orthonormal basis of the plane perpendicular to L
+    double ax[3] = {1, 0, 0};
+    if (std::fabs(Lx) > std::fabs(Ly) && std::fabs(Lx) > std::fabs(Lz)) { ax[0] = 0; ax[1] = 1; }
+    double e1[3] = {Ly * ax[2] - Lz * ax[1], Lz * ax[0] - Lx * ax[2], Lx * ax[1] - Ly * ax[0]};
+    const double n1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    for (double& v : e1) v /= n1;
+    double e2[3] = {(Ly * e1[2] - Lz * e1[1]) / ln, (Lz * e1[0] - Lx * e1[2]) / ln, (Lx * e1[1] - Ly * e1[0]) / ln};
+    for (int k = 0; k < 3; ++k) {
+        G.e1[k] = (float)e1[k];
+        G.e2[k] = (float)e2[k];
+    }
+    const size_t nEnt = (size_t)L.nGroups * 4;
+    // P0: twice the reach of the ordinary (non-huge) spheres, so that practically every hit point qualifies
+    std::vector<double> rs;
+    for (size_t e = 0; e < nEnt; ++e)
+        if (L.orig[e] != 0xffffffffu) rs.push_back(sp[L.orig[e]].r);
+    if (rs.empty()) return;
+    std::nth_element(rs.begin(), rs.begin() + rs.size() / 2, rs.end());
+    const double med = rs[rs.size() / 2];
+    double reach = 0;
+    for (size_t e = 0; e < nEnt; ++e) {
+        if (L.orig[e] == 0xffffffffu) continue;
+        const rt_sphere& q = sp[L.orig[e]];
+        if (q.r > 4.0 * med) continue;
+        reach = std::max(reach, std::sqrt((double)q.cx * q.cx + (double)q.cy * q.cy + (double)q.cz * q.cz) + q.r);
+    }
+    const double P0 = 2.0 * reach + 8.0 * med + 1.0;
+    const double eps = 5.9604644775390625e-08;
+    struct Foot { double u, v, rho; uint16_t entry; };
+    std::vector<Foot> feet;
+    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+    std::vector<double> rhos;
+    for (size_t e = 0; e < nEnt; ++e) {
+        if (L.orig[e] == 0xffffffffu) continue;
+        const rt_sphere& q = sp[L.orig[e]];
+        // the device projects with the FLOAT basis; use the same vectors here
+        const double u = q.cx * (double)G.e1[0] + q.cy * (double)G.e1[1] + q.cz * (double)G.e1[2];
+        const double v = q.cx * (double)G.e2[0] + q.cy * (double)G.e2[1] + q.cz * (double)G.e2[2];
+        const double cn = std::sqrt((double)q.cx * q.cx + (double)q.cy * q.cy + (double)q.cz * q.cz);
+        const double rho = std::sqrt((double)q.r * q.r + 64.0 * eps * (2.0 * P0 * P0 + 2.0 * cn * cn + (double)q.r * q.r)) * (1.0 + 1e-4) +
+                           1e-5 * (P0 + cn + 1.0);
+        feet.push_back({u, v, rho, (uint16_t)e});
+        if (q.r <= 4.0 * med) {
+            lo[0] = std::min(lo[0], u - rho); hi[0] = std::max(hi[0], u + rho);
+            lo[1] = std::min(lo[1], v - rho); hi[1] = std::max(hi[1], v + rho);
+            rhos.push_back(rho);
+        }
+    }
+    if (rhos.empty()) {  // only huge spheres: everything goes to the global list, a 1x1 grid
+        lo[0] = lo[1] = -1.0;
+        hi[0] = hi[1] = 1.0;
+        rhos.push_back(1.0);
+    }
+    std::nth_element(rhos.begin(), rhos.begin() + rhos.size() / 2, rhos.end());
+    const double ext = std::max(hi[0] - lo[0], hi[1] - lo[1]);
+    double cell = std::max(2.0 * rhos[rhos.size() / 2], ext / 64.0);
+    G.nx = (uint32_t)std::min(64.0, std::max(1.0, std::ceil((hi[0] - lo[0]) / cell)));
+    G.ny = (uint32_t)std::min(64.0, std::max(1.0, std::ceil((hi[1] - lo[1]) / cell)));
+    G.u0 = (float)lo[0];
+    G.v0 = (float)lo[1];
+    G.invCell = (float)(1.0 / cell);
+    // cell of a coordinate exactly as the device computes it (float), widened by one ulp-ish slack through rho
+    auto cellOf = [&](double x, float x0, uint32_t n) -> long {
+        const double f = (x - (double)x0) * (double)G.invCell;
+        return (long)std::floor(f);
+    };
+    std::vector<std::vector<uint16_t>> cells((size_t)G.nx * G.ny);
+    const size_t ncell = cells.size();
+    for (const Foot& f : feet) {
+        long x0 = cellOf(f.u - f.rho, G.u0, G.nx) - 1, x1 = cellOf(f.u + f.rho, G.u0, G.nx) + 1;  // +-1 cell: float cell arithmetic slack
+        long y0 = cellOf(f.v - f.rho, G.v0, G.ny) - 1, y1 = cellOf(f.v + f.rho, G.v0, G.ny) + 1;
+        const bool outside = x1 < 0 || y1 < 0 || x0 >= (long)G.nx || y0 >= (long)G.ny;
+        x0 = std::max(0L, x0); y0 = std::max(0L, y0);
+        x1 = std::min((long)G.nx - 1, x1); y1 = std::min((long)G.ny - 1, y1);
+        const bool spills = (f.u - f.rho < lo[0]) || (f.u + f.rho > hi[0]) || (f.v - f.rho < lo[1]) || (f.v + f.rho > hi[1]);
+        const size_t covered = outside ? 0 : (size_t)(x1 - x0 + 1) * (size_t)(y1 - y0 + 1);
+        // a footprint reaching beyond the grid can shadow points outside it: it must be tested for every query
+        if (spills || covered * 8 > ncell) {
+            G.global.push_back(f.entry);
+            continue;
+        }
+        for (long y = y0; y <= y1; ++y)
+            for (long x = x0; x <= x1; ++x) cells[(size_t)y * G.nx + x].push_back(f.entry);
+    }
+    size_t total = 0;
+    for (const auto& c : cells) total += c.size();
+    if (total >= 65535 || G.global.size() > 64) return;  // pathological: keep the scan
+    G.cellStart.resize(ncell + 1);
+    G.entries.reserve(total);
+    for (size_t c = 0; c < ncell; ++c) {
+        G.cellStart[c] = (uint16_t)G.entries.size();
+        G.entries.insert(G.entries.end(), cells[c].begin(), cells[c].end());
+    }
+    G.cellStart[ncell] = (uint16_t)G.entries.size();
+    G.p0sq = (float)(P0 * P0 * (1.0 - 1e-6));
+    G.enabled = true;
+}
+
 static size_t LdsBytesFor(uint32_t n, uint32_t nPadded, bool mats) {
     return (size_t)nPadded * (16 + 4) + (mats ? (size_t)n * 48 : 0) + (size_t)((n + 3) / 4) * 16;
 }
@@ -261,7 +379,10 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     const size_t candBytes = (size_t)wavesPerBlock * (tree ? rtd::kWaveCandBytes : rtd::kWaveListBytes);
     const bool flat = !tree && useLds && ctx->useMfma && (candBytes + lds + MfmaOpsBytesFor(topCnt)) <= 160 * 1024;
     const bool ldsTables = useLds && !tree;
-    const size_t ldsBytes = candBytes + (ldsTables ? lds : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0);
+    size_t sgBytes = (flat && tp.sg_enabled) ? (((size_t)tp.sg_nx * tp.sg_ny + 1 + tp.sg_nentries + tp.sg_nglobal) * 2 + 15) / 16 * 16 : 0;
+    if (candBytes + lds + MfmaOpsBytesFor(topCnt) + sgBytes > 160 * 1024) sgBytes = 0;  // index stays in global memory (L2)
+    tp.sg_in_lds = sgBytes ? 1u : 0u;
+    const size_t ldsBytes = candBytes + (ldsTables ? lds : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0) + sgBytes;
 #define RT_LAUNCH(LDS, T, M)                                                                                                   \
     do {                                                                                                                      \
         if (ldsBytes > 48 * 1024)                                                                                             \
@@ -327,6 +448,7 @@ int rt_create(int device_ordinal, rt_ctx** out) {
         const char* scan = std::getenv("RT_SCAN");
         ctx->useMfma = !(scan && std::strcmp(scan, "valu") == 0);
         ctx->matsInLds = EnvU32("RT_MATS_LDS", 1) != 0;
+        ctx->useShadowGrid = EnvU32("RT_SHADOW_GRID", 1) != 0;
         ctx->treeTop = EnvU32("RT_TREE_TOP", 128);
         if (ctx->treeTop < 4 || ctx->treeTop > 128) ctx->treeTop = 128;
     }
@@ -358,6 +480,9 @@ void rt_destroy(rt_ctx* ctx) {
     ctx->scan.Release();
     ctx->orig.Release();
     ctx->tree.Release();
+    ctx->sgCells.Release();
+    ctx->sgEntries.Release();
+    ctx->sgGlobal.Release();
     ctx->radius.Release();
     ctx->mats.Release();
     ctx->hdr.Release();
@@ -408,8 +533,37 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     RT_HIP(hipMemcpy(ctx->radius.ptr, rad.data(), n * sizeof(float), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->mats.ptr, materials, n * sizeof(rt_material), hipMemcpyHostToDevice));
 
+    ShadowGrid SG;
+    if (ctx->useShadowGrid) BuildShadowGrid(spheres, L, sun->direction, SG);
+    if (SG.enabled) {
+        if ((rc = ctx->sgCells.Reserve(SG.cellStart.size())) != RT_OK) return rc;
+        if ((rc = ctx->sgEntries.Reserve(SG.entries.size() + 1)) != RT_OK) return rc;
+        if ((rc = ctx->sgGlobal.Reserve(SG.global.size() + 1)) != RT_OK) return rc;
+        RT_HIP(hipMemcpy(ctx->sgCells.ptr, SG.cellStart.data(), SG.cellStart.size() * 2, hipMemcpyHostToDevice));
+        if (!SG.entries.empty()) RT_HIP(hipMemcpy(ctx->sgEntries.ptr, SG.entries.data(), SG.entries.size() * 2, hipMemcpyHostToDevice));
+        if (!SG.global.empty()) RT_HIP(hipMemcpy(ctx->sgGlobal.ptr, SG.global.data(), SG.global.size() * 2, hipMemcpyHostToDevice));
+    }
+
     rtd::TraceParams& b = ctx->base;
     b = rtd::TraceParams{};
+    b.sg_enabled = SG.enabled ? 1u : 0u;
+    if (SG.enabled) {
+        b.sg_cell_start = ctx->sgCells.ptr;
+        b.sg_entries = ctx->sgEntries.ptr;
+        b.sg_global = ctx->sgGlobal.ptr;
+        b.sg_nx = SG.nx;
+        b.sg_ny = SG.ny;
+        b.sg_nglobal = (uint32_t)SG.global.size();
+        b.sg_nentries = (uint32_t)SG.entries.size();
+        for (int k = 0; k < 3; ++k) {
+            b.sg_e1[k] = SG.e1[k];
+            b.sg_e2[k] = SG.e2[k];
+        }
+        b.sg_u0 = SG.u0;
+        b.sg_v0 = SG.v0;
+        b.sg_inv_cell = SG.invCell;
+        b.sg_p0sq = SG.p0sq;
+    }
     b.scan = ctx->scan.ptr;
     b.orig = ctx->orig.ptr;
     b.tree = ctx->tree.ptr;

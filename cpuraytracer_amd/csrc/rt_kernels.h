@@ -79,6 +79,13 @@ struct TraceParams {
     uint32_t mats_in_lds;      // stage the material table into LDS (else it is read through L2)
     float bound_norm;          // max over groups of |C| + R (scale of the filter's behind-the-origin threshold)
     uint32_t n_padded;         // 4 * n_groups + 4
+    // Exact shadow index for the (single, directional) sun: spheres binned by their footprint in the plane
+    // perpendicular to the light.  Valid for hit points with |p|^2 <= sg_p0sq.
+    const uint16_t* sg_cell_start;  // [sg_nx * sg_ny + 1]
+    const uint16_t* sg_entries;     // clustered entry indices per cell
+    const uint16_t* sg_global;      // entries tested for every query (footprints covering much of the grid)
+    uint32_t sg_nx, sg_ny, sg_nglobal, sg_nentries, sg_enabled, sg_in_lds;
+    float sg_e1[3], sg_e2[3], sg_u0, sg_v0, sg_inv_cell, sg_p0sq;
     float cam_o[3], cam_x[3], cam_y[3], cam_oip[3];
     float aperture, focal;
     float sun_dir[3], sun_rad[3];  // sun_rad = luminance * colour (light.cpp:27, left factor)
@@ -670,6 +677,46 @@ RT_DEV bool scatter_and_shade(const TraceParams& p, const Mat& m, V3 rd, V3 pos,
     return scattered;
 }
 
+// ------------------------------------------------------------- shadow rays (A13) without a scan
+// DirectionalLight::Shade asks whether ANY sphere yields an acceptable root for the ray (hit.pos, L)
+// (light.cpp:13-15 -> BvhNode::Intersect used as any-hit).  L is the same for every shadow ray, so the
+// host bins the spheres by their footprint (a disc) in the plane perpendicular to L; a query evaluates
+// Sphere::Intersect's reference-order arithmetic only for the spheres whose inflated footprint covers
+// the point's cell, plus a short list of spheres that cover much of the grid (the floor).  A sphere the
+// reference test accepts has its centre within sqrt(r^2 + E/a) of the ray's line, E <= 16 eps a (2|p|^2 +
+// 2|c|^2 + r^2); the footprints are inflated for that with |p| <= P0 (and for the rounding of the
+// projection), so inside that radius the answer is exactly the reference's.  Points farther out fall
+// back to the shadow scan.
+RT_DEV bool sphere_any_hit(const float4 S, V3 o, V3 d, float a) {
+    const float ocx = o.x - S.x;
+    const float ocy = o.y - S.y;
+    const float ocz = o.z - S.z;
+    const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
+    const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;
+    const float disc = b * b - a * cc;
+    if (disc > 0.f) {  // ray-tracing.cpp:54-71
+        const float sq = __builtin_sqrtf(disc);
+        if ((-b - sq) / a > 0.001f) return true;
+        if ((-b + sq) / a > 0.001f) return true;
+    }
+    return false;
+}
+
+RT_DEV bool shadow_query(const TraceParams& p, const float4* __restrict__ tab, const uint16_t* __restrict__ cellStart,
+                         const uint16_t* __restrict__ entries, const uint16_t* __restrict__ glob, V3 pos, V3 L, float aL) {
+    bool occluded = false;
+    for (uint32_t k = 0; k < p.sg_nglobal && !occluded; ++k) occluded = sphere_any_hit(tab[glob[k]], pos, L, aL);
+    const float u = dot3(pos, v3(p.sg_e1[0], p.sg_e1[1], p.sg_e1[2]));
+    const float v = dot3(pos, v3(p.sg_e2[0], p.sg_e2[1], p.sg_e2[2]));
+    const float fx = (u - p.sg_u0) * p.sg_inv_cell, fy = (v - p.sg_v0) * p.sg_inv_cell;
+    if (!occluded && fx >= 0.f && fy >= 0.f && fx < (float)p.sg_nx && fy < (float)p.sg_ny) {
+        const uint32_t c = (uint32_t)fy * p.sg_nx + (uint32_t)fx;
+        const uint32_t e1 = cellStart[c + 1];
+        for (uint32_t e = cellStart[c]; e < e1 && !occluded; ++e) occluded = sphere_any_hit(tab[entries[e]], pos, L, aL);
+    }
+    return occluded;
+}
+
 // lanes below mine that are set in mask
 RT_DEV uint32_t prefix_count(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -700,6 +747,9 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
     constexpr uint32_t kWaveRegion = kScan == 2 ? kWaveCandBytes : kWaveListBytes;  // the descent stack only exists in tree mode
     float4* tabBase = smem + (kThreads / kWaveSize) * (kWaveRegion / 16);
     const float* mfmaOps = nullptr;
+    const uint16_t* sgCell = p.sg_cell_start;
+    const uint16_t* sgEntries = p.sg_entries;
+    const uint16_t* sgGlobal = p.sg_global;
     const uint32_t topLevel = p.n_levels - 1u;
     const uint32_t nTop = p.level_cnt[topLevel];
     const uint32_t nTiles = (nTop + 31u) / 32u;
@@ -721,6 +771,16 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
             float* ldsOps = ldsRad + ((p.n + 3u) & ~3u);
             build_mfma_operands(p.tree + p.level_off[topLevel], nTop, nTiles, ldsOps, threadIdx.x, blockDim.x);
             mfmaOps = ldsOps;
+            if (p.sg_enabled && p.sg_in_lds) {  // shadow index after the operand image
+                uint16_t* g = reinterpret_cast<uint16_t*>(ldsOps + (size_t)nTiles * 256);
+                const uint32_t nc = p.sg_nx * p.sg_ny + 1u;
+                for (uint32_t k = threadIdx.x; k < nc; k += blockDim.x) g[k] = p.sg_cell_start[k];
+                for (uint32_t k = threadIdx.x; k < p.sg_nentries; k += blockDim.x) g[nc + k] = p.sg_entries[k];
+                for (uint32_t k = threadIdx.x; k < p.sg_nglobal; k += blockDim.x) g[nc + p.sg_nentries + k] = p.sg_global[k];
+                sgCell = g;
+                sgEntries = g + nc;
+                sgGlobal = g + nc + p.sg_nentries;
+            }
         }
         __syncthreads();
         scanTab = ldsScan;
@@ -739,6 +799,7 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
     uint16_t* waveCand = candBase + (threadIdx.x / kWaveSize) * (kWaveRegion / 2);
     uint16_t* cand = waveCand + lane;
     const V3 sunDir = v3(p.sun_dir[0], p.sun_dir[1], p.sun_dir[2]);
+    const float aSun = dot3(sunDir, sunDir);  // the `a` of every shadow ray (ray-tracing.cpp:46)
 
     // per-lane path state
     V3 ro = v3(0.f, 0.f, 0.f), rd = v3(0.f, 0.f, 1.f);  // current ray
@@ -841,16 +902,34 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
                 const V3 nrm = (pos - center) / radius;  // ray-tracing.cpp:58
                 V3 atten, local, localOcc;
                 const bool scattered = scatter_and_shade(p, m, rd, pos, nrm, draws, atten, nextDir, local, localOcc);
-                pend = thr * local;
-                // a path that does not scatter ends here, so its nextDir registers carry throughput * (Emit + 0),
-                // the value the reference adds when the sun is occluded (0 for every non-emissive material)
-                pathScattered = scattered;
-                if (!scattered) nextDir = thr * localOcc;
-                contAfterShadow = (depth < p.max_depth) && scattered;  // spheres-app.cpp:247
-                thr = thr * atten;
-                ro = pos;  // shadow ray and scattered ray both start at hit.pos
-                rd = sunDir;
-                state = kNeedShadow;
+                const bool cont = (depth < p.max_depth) && scattered;  // spheres-app.cpp:247
+                if (p.sg_enabled && dot3(pos, pos) <= p.sg_p0sq) {
+                    // shadow ray answered by the exact footprint index: no second scan for this hit
+                    const bool occluded = shadow_query(p, scanTab, sgCell, sgEntries, sgGlobal, pos, sunDir, aSun);
+                    ++nTrav;  // the shadow ray still counts as a traversal of the scene (matches the oracle's counter)
+                    ++pathTrav;
+                    if (!occluded) rad = rad + thr * local;           // radiance += throughput * (Emit + Shade)
+                    else if (!scattered) rad = rad + thr * localOcc;  // occluded: throughput * (Emit + 0)
+                    if (cont) {
+                        thr = thr * atten;
+                        ro = pos;
+                        rd = nextDir;
+                        ++depth;
+                    } else {
+                        finished = true;
+                    }
+                } else {
+                    pend = thr * local;
+                    // a path that does not scatter ends here, so its nextDir registers carry throughput * (Emit + 0),
+                    // the value the reference adds when the sun is occluded (0 for every non-emissive material)
+                    pathScattered = scattered;
+                    if (!scattered) nextDir = thr * localOcc;
+                    contAfterShadow = cont;
+                    thr = thr * atten;
+                    ro = pos;  // shadow ray and scattered ray both start at hit.pos
+                    rd = sunDir;
+                    state = kNeedShadow;
+                }
             }
         } else if (state == kNeedShadow) {
             if (idx < 0) rad = rad + pend;              // sun visible: radiance += throughput * (Emit + Shade)
