@@ -580,11 +580,10 @@ struct ScriptedDraws {
 // Emit + Shade with the sun visible and localOccluded = Emit + 0 (the caller adds one of the two once the
 // shadow scan has decided; Emit is non-zero only for Emissive spheres, which never scatter).
 template <class Draws>
-RT_DEV bool scatter_and_shade(const TraceParams& p, const Mat& m, V3 rd, V3 pos, V3 nrm, Draws& draws, V3& atten, V3& outDir,
-                              V3& local, V3& localOccluded) {
+RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V3& outDir, V3& tex) {
     const float uvx = 0.5f * nrm.x + 0.5f;  // Sphere::ComputeUV, ray-tracing.cpp:26-40
     const float uvy = 0.5f * nrm.z + 0.5f;
-    const V3 tex = eval_texture(m, uvx, uvy);
+    tex = eval_texture(m, uvx, uvy);
     bool scattered = false;
     atten = v3(1.f, 1.f, 1.f);
     outDir = v3(0.f, 0.f, 0.f);
@@ -648,6 +647,16 @@ RT_DEV bool scatter_and_shade(const TraceParams& p, const Mat& m, V3 rd, V3 pos,
         }
     }
 
+    return scattered;
+}
+
+// Emit + DirectionalLight::Shade's unoccluded value (light.cpp:21-40) and Emit + 0 (its value when occluded).
+RT_DEV void shade_value(const TraceParams& p, const Mat& m, V3 tex, V3 pos, V3 nrm, bool wantShade, V3& local, V3& localOccluded) {
+    V3 emit = v3(0.f, 0.f, 0.f);
+    if (m.type == RT_MAT_EMISSIVE) emit = m.luminance * tex;  // material.cpp:172-175; 0 for every other material
+    localOccluded = emit + v3(0.f, 0.f, 0.f);  // Shade returns XM_Zero when the sun is occluded (light.cpp:15-18)
+    local = localOccluded;
+    if (!wantShade) return;
     // Material getters (material.h:26-29,42-45,59-62,76-79)
     V3 albedo = v3(0.f, 0.f, 0.f), f0 = v3(0.04f, 0.04f, 0.04f);
     if (m.type == RT_MAT_DIELECTRIC_OPAQUE) albedo = tex;
@@ -669,11 +678,16 @@ RT_DEV bool scatter_and_shade(const TraceParams& p, const Mat& m, V3 rd, V3 pos,
     const V3 reflectance = f0 + (one - f0) * p5;
     const V3 spec = ((reflectance * 0.125f) * (smooth + 8.f)) * ps;
     const V3 shade = radianceIn * (albedo + spec);
-    // Emit (0 for every scene material; Emissive spheres would emit luminance*colour) + Shade
-    V3 emit = v3(0.f, 0.f, 0.f);
-    if (m.type == RT_MAT_EMISSIVE) emit = m.luminance * tex;
     local = emit + shade;
-    localOccluded = emit + v3(0.f, 0.f, 0.f);  // Shade returns XM_Zero when the sun is occluded (light.cpp:15-18)
+}
+
+// Scatter, then Emit + Shade with the sun assumed visible (the scan-based shadow path decides later).
+template <class Draws>
+RT_DEV bool scatter_and_shade(const TraceParams& p, const Mat& m, V3 rd, V3 pos, V3 nrm, Draws& draws, V3& atten, V3& outDir,
+                              V3& local, V3& localOccluded) {
+    V3 tex;
+    const bool scattered = scatter_only(m, rd, nrm, draws, atten, outDir, tex);
+    shade_value(p, m, tex, pos, nrm, true, local, localOccluded);
     return scattered;
 }
 
@@ -900,12 +914,16 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
                 const V3 center = v3(S.x, S.y, S.z);
                 const V3 pos = tmin * rd + ro;          // XMVectorMultiplyAdd(t, dir, origin), ray-tracing.cpp:57
                 const V3 nrm = (pos - center) / radius;  // ray-tracing.cpp:58
-                V3 atten, local, localOcc;
-                const bool scattered = scatter_and_shade(p, m, rd, pos, nrm, draws, atten, nextDir, local, localOcc);
+                V3 atten, local, localOcc, tex;
+                const bool scattered = scatter_only(m, rd, nrm, draws, atten, nextDir, tex);  // Scatter first: it draws (spheres-app.cpp:246)
                 const bool cont = (depth < p.max_depth) && scattered;  // spheres-app.cpp:247
-                if (p.sg_enabled && dot3(pos, pos) <= p.sg_p0sq) {
+                const bool useIndex = p.sg_enabled && dot3(pos, pos) <= p.sg_p0sq;
+                bool occluded = false;
+                if (useIndex) occluded = shadow_query(p, scanTab, sgCell, sgEntries, sgGlobal, pos, sunDir, aSun);
+                // the Blinn-Phong value (two normalisations, two pows) is only needed when the sun is visible or unknown
+                shade_value(p, m, tex, pos, nrm, !occluded, local, localOcc);
+                if (useIndex) {
                     // shadow ray answered by the exact footprint index: no second scan for this hit
-                    const bool occluded = shadow_query(p, scanTab, sgCell, sgEntries, sgGlobal, pos, sunDir, aSun);
                     ++nTrav;  // the shadow ray still counts as a traversal of the scene (matches the oracle's counter)
                     ++pathTrav;
                     if (!occluded) rad = rad + thr * local;           // radiance += throughput * (Emit + Shade)
