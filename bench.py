@@ -191,9 +191,10 @@ def main():
                          "frac": achieved_tflops / PEAK_VALU_TFLOPS, "traffic": traffic, "launch_ms": avg_ms,
                          "algorithmic": "18 flop x %d spheres x %.0f list scans per launch (SURVEY.md 8d; unfused fp32, peak = 157.3/2)"
                                         % (n_spheres, avg_trav),
-                         "note": "frac > 1 is real: ALGORITHMIC flops of an exhaustive list scan over the time of a kernel that culls "
-                                 "(group-bound filter on the matrix cores + exact VALU resolve of the survivors). Executed-instruction "
-                                 "view: profiles/r01_pmc_summary.json (VALU issue ~63 % busy, f32 MFMA ~16 %)"},
+                         "note": "frac > 1 is real: ALGORITHMIC flops of exhaustive list scans (SURVEY 8d) over the time of a kernel that "
+                                 "culls (group-bound filter on the matrix cores, exact VALU resolve of the survivors, shadow rays "
+                                 "answered by an exact footprint index). Executed-instruction view: profiles/r01_pmc_summary.json "
+                                 "(VALU issue ~64 % busy, f32 MFMA ~14 %, lane utilisation 0.45)"},
             "hbm_read_equivalent": {"bound": "hbm", "achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": achieved_gbs / PEAK_HBM_GBS,
                                     "note": "16 B sphere record x tests / kernel time; served from LDS, so it may exceed the HBM roofline"},
