@@ -382,7 +382,10 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     size_t sgBytes = (flat && tp.sg_enabled) ? (((size_t)tp.sg_nx * tp.sg_ny + 1 + tp.sg_nentries + tp.sg_nglobal) * 2 + 15) / 16 * 16 : 0;
     if (candBytes + lds + MfmaOpsBytesFor(topCnt) + sgBytes > 160 * 1024) sgBytes = 0;  // index stays in global memory (L2)
     tp.sg_in_lds = sgBytes ? 1u : 0u;
-    const size_t ldsBytes = candBytes + (ldsTables ? lds : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0) + sgBytes;
+    size_t treeBytes = tree ? (size_t)(tp.level_off[tp.n_levels - 1] + topCnt) * 16 : 0;
+    if (candBytes + MfmaOpsBytesFor(topCnt) + treeBytes > 160 * 1024) treeBytes = 0;
+    tp.tree_in_lds = treeBytes ? 1u : 0u;
+    const size_t ldsBytes = candBytes + (ldsTables ? lds : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0) + sgBytes + treeBytes;
 #define RT_LAUNCH(LDS, T, M)                                                                                                   \
     do {                                                                                                                      \
         if (ldsBytes > 48 * 1024)                                                                                             \

@@ -72,6 +72,7 @@ struct TraceParams {
     const float4* tree;        // all levels, level 0 first: Cx, Cy, Cz, |C|^2 - Rf^2
     uint32_t level_off[kMaxLevels], level_cnt[kMaxLevels];
     uint32_t n_levels;
+    uint32_t tree_in_lds;      // tree mode: stage every level of bounds into LDS (else the descent reads them through L2)
     const float* radius;       // [n] by original index
     const rt_material* mats;   // [n] by original index
     uint32_t n;                // real spheres
@@ -761,6 +762,7 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
     constexpr uint32_t kWaveRegion = kScan == 2 ? kWaveCandBytes : kWaveListBytes;  // the descent stack only exists in tree mode
     float4* tabBase = smem + (kThreads / kWaveSize) * (kWaveRegion / 16);
     const float* mfmaOps = nullptr;
+    const float4* treeTab = p.tree;
     const uint16_t* sgCell = p.sg_cell_start;
     const uint16_t* sgEntries = p.sg_entries;
     const uint16_t* sgGlobal = p.sg_global;
@@ -802,10 +804,16 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
         radTab = ldsRad;
         if (p.mats_in_lds) matTab = reinterpret_cast<const rt_material*>(ldsMat);
     } else if (kMfma) {
-        // tables stay in global memory; only the top level's operand image lives in LDS
+        // exact tables stay in global memory (L2); the top level's operand image and, when they fit, all bounds live in LDS
         float* ldsOps = reinterpret_cast<float*>(tabBase);
         build_mfma_operands(p.tree + p.level_off[topLevel], nTop, nTiles, ldsOps, threadIdx.x, blockDim.x);
         mfmaOps = ldsOps;
+        if (p.tree_in_lds) {
+            float4* ldsTree = reinterpret_cast<float4*>(ldsOps + (size_t)nTiles * 256);
+            const uint32_t nNodes = p.level_off[topLevel] + nTop;
+            for (uint32_t k = threadIdx.x; k < nNodes; k += blockDim.x) ldsTree[k] = p.tree[k];
+            treeTab = ldsTree;
+        }
         __syncthreads();
     }
 
@@ -886,7 +894,7 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
         if (kMfma) {
             // every lane takes part: lane l also supplies operands for, and filters half the spheres of,
             // the ray owned by lane l^32, whether or not its own ray is live
-            scan_list_mfma<kScan == 2>(scanTab, origTab, mfmaOps, nTiles, nTop, p.tree, p.level_off, p.n_levels, p.bound_norm, ro, rd,
+            scan_list_mfma<kScan == 2>(scanTab, origTab, mfmaOps, nTiles, nTop, treeTab, p.level_off, p.n_levels, p.bound_norm, ro, rd,
                                        state != kIdle, tmin, idx, waveCand, lane, dbgScan);
         } else if (state != kIdle) {
             scan_list_deferred(scanTab, origTab, p.n_padded, ro, rd, tmin, idx, cand);
