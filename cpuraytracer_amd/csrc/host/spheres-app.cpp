@@ -30,7 +30,10 @@ void RayTracingApp::InitBuffers() {  // app.cpp:112-119
 }
 int RayTracingApp::Run(uint32_t frames) noexcept {  // app.cpp:56-76
     try {
-        for (uint32_t f = 0; f < frames; ++f) OnRender();
+        for (uint32_t f = 0; f < frames; ++f) {
+            BeforeFrame(f, frames);
+            OnRender();
+        }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "spheres: %s\n", e.what());
         return 1;
@@ -169,10 +172,15 @@ size_t SpheresApp::DrawBitmap() {  // spheres-app.cpp:163-222
     const uint32_t s0 = (uint32_t)m_sampleCount + 1;  // ++m_sampleCount (:168): first frame uses index 1
     const uint32_t s1 = s0 + AppSettings.samplesPerFrame;
     // GenerateRays + trace (:171-184) and the tonemap (:196-214) on the device
-    RT_CALL(rt_render(m_device, W, H, rs, s0, s1, (uint32_t)AppSettings.k_recursionDepth, AppSettings.renderSeed, &m_lastStats));
+    // per-frame statistics cost a host wait; a quiet progressive run stays asynchronous until the last frame
+    rt_stats* wantStats = (m_quiet && !m_lastFrame) ? nullptr : &m_lastStats;
+    RT_CALL(rt_render(m_device, W, H, rs, s0, s1, (uint32_t)AppSettings.k_recursionDepth, AppSettings.renderSeed, wantStats));
+    if (!wantStats) m_lastStats.local_rows = rt_rowset_local_rows(rs);
     m_sampleCount += AppSettings.samplesPerFrame;
-    RT_CALL(rt_resolve(m_device, (uint32_t)m_sampleCount));
-    m_lastStats.ms_resolve = rt_last_resolve_ms(m_device);
+    if (wantStats) {  // the tonemap feeds the display in the reference; headless and quiet, only the last frame needs it
+        RT_CALL(rt_resolve(m_device, (uint32_t)m_sampleCount));
+        m_lastStats.ms_resolve = rt_last_resolve_ms(m_device);
+    }
     return (size_t)W * m_lastStats.local_rows * AppSettings.samplesPerFrame;
 }
 

@@ -32,6 +32,7 @@ public:
     virtual ~RayTracingApp() = default;
     virtual void Initialize(int deviceOrdinal);
     virtual int Run(uint32_t frames) noexcept;  // app.cpp:56-76: OnRender whenever idle, here `frames` times
+    virtual void BeforeFrame(uint32_t frame, uint32_t frames) {}
 
 protected:
     virtual void OnInitialize() = 0;
@@ -62,7 +63,9 @@ public:
     const rt_stats& LastStats() const { return m_lastStats; }
     void SetRowset(rt_rowset rs) { m_rowset = rs; m_hasRowset = true; }
     void SetQuiet(bool q) { m_quiet = q; }
+    void SetLastFrame(bool l) { m_lastFrame = l; }
 
+    void BeforeFrame(uint32_t frame, uint32_t frames) override { m_lastFrame = frame + 1 == frames; }
     void OnInitialize() override;  // public so tools can build the scene without a device
     void OnRender() override;
     int GetBackBufferWidth() const override;
@@ -87,6 +90,7 @@ private:
     rt_rowset m_rowset{};
     bool m_hasRowset = false;
     bool m_quiet = false;
+    bool m_lastFrame = true;
     mutable double m_totalSeconds = 0.0;
     rt_stats m_lastStats{};
 };

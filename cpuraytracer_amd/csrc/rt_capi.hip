@@ -691,13 +691,18 @@ int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, ui
                            npix, spp);
         RT_HIP(hipGetLastError());
         RT_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-        RT_HIP(hipEventSynchronize(ctx->ev[2]));
-        float a = 0.f, b = 0.f;
-        RT_HIP(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
-        RT_HIP(hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
-        msTrace += a;
-        msAcc += b;
         ++passes;
+        // Without a stats request the call stays asynchronous on the stream (progressive 1-spp frames are launch
+        // bound: ~0.2 ms of GPU work each); with one it waits for the pass to read the event timers.  A multi-pass
+        // render must wait anyway before the next pass reuses the workspace's event objects.
+        if (out_stats || s + sppPass < s1) {
+            RT_HIP(hipEventSynchronize(ctx->ev[2]));
+            float a = 0.f, b = 0.f;
+            RT_HIP(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+            RT_HIP(hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
+            msTrace += a;
+            msAcc += b;
+        }
     }
     ctx->accumulated += sppTotal;
 

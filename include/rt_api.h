@@ -151,7 +151,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
  * s0 == 1 (or after rt_clear) starts a new accumulation, a call whose s0 equals
  * the previous s1 continues it (progressive refinement, app.h:26 + spheres-app.h:42).
  * Material random draws come from a per-(pixel,s) xoshiro128** stream seeded from
- * (seed, global pixel id, s) — see DESIGN.md "RNG contract". */
+ * (seed, global pixel id, s) — see DESIGN.md "RNG contract".  With out_stats == NULL the call only enqueues work
+ * on the context's stream (no host wait); with out_stats it waits for the kernels to read their timers. */
 int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1,
               uint32_t max_depth, uint64_t seed, rt_stats* out_stats);
 
