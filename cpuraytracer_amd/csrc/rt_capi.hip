@@ -130,7 +130,7 @@ struct SceneLayout {
 // Conservative bounding sphere of a set of spheres, in the filter's (C, |C|^2 - Rf^2) form.
 static float4 BoundOf(const rt_sphere* sp, const std::vector<uint32_t>& ids, float* normOut) {
     if (ids.empty()) return make_float4(0.f, 0.f, 0.f, 1e30f);  // never a candidate
-    const double kEps = 2048.0 * 5.9604644775390625e-08;  // K * eps, K = 2048 (rt_kernels.h kMarginRel)
+    const double kEps = (double)rtd::kMarginK * 5.9604644775390625e-08;  // K * eps (rt_kernels.h kMarginRel)
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (uint32_t k : ids) {
         const double c[3] = {sp[k].cx, sp[k].cy, sp[k].cz};
@@ -357,7 +357,7 @@ static void BuildShadowGrid(const rt_sphere* sp, const SceneLayout& L, const flo
 static size_t LdsBytesFor(uint32_t n, uint32_t nPadded, bool mats) {
     return (size_t)nPadded * (16 + 4) + (mats ? (size_t)n * 48 : 0) + (size_t)((n + 3) / 4) * 16;
 }
-static size_t MfmaOpsBytesFor(uint32_t nGroups) { return (size_t)((nGroups + 31u) / 32u) * 4 * 64 * 4; }
+static size_t MfmaOpsBytesFor(uint32_t nGroups) { return (size_t)((nGroups + 31u) / 32u) * rtd::kOpsPerTile * 4; }
 
 // Launch the megakernel over total paths described by tp.
 static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
@@ -958,12 +958,12 @@ int rt_unit_layout(const rt_sphere* spheres, uint32_t n, uint32_t cap_groups, ui
 
 #ifdef RT_STAMPS
 // Diagnostic build only: read and clear the section clocks (see rt_kernels.h g_dbg).
-int rt_debug_stamps(rt_ctx* ctx, unsigned long long out[8]) {
+int rt_debug_stamps(rt_ctx* ctx, unsigned long long out[16]) {
     if (!ctx || !out) return Fail(RT_ERR_INVALID_ARG, "rt_debug_stamps: invalid argument");
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipStreamSynchronize(ctx->stream));
-    RT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(rtd::g_dbg), 8 * sizeof(unsigned long long)));
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    RT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(rtd::g_dbg), 16 * sizeof(unsigned long long)));
+    unsigned long long z[16] = {0};
     RT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_dbg), z, sizeof(z)));
     return RT_OK;
 }

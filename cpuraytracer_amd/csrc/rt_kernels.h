@@ -41,7 +41,8 @@ namespace rtd {
 // Diagnostic build only (-DRT_STAMPS): per-section shader-clock sums go to g_dbg[], which no kernel reads.
 // The shipped library is built without it.
 #ifdef RT_STAMPS
-static __device__ unsigned long long g_dbg[8];  // refill, scan, transitions, iterations, filter, resolve, resolve items, -
+static __device__ unsigned long long g_dbg[16];  // refill, scan, transitions, iterations, filter, resolve, resolve items, max items,
+                                                 // phase A cycles, phase B cycles, A iterations, B iterations, scatter, shadow query, shade, -
 RT_DEV unsigned long long rt_stamp() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -284,6 +285,29 @@ RT_DEV void resolve_group(const float4* __restrict__ tab, const uint32_t* __rest
     }
 }
 
+// Phase A of the two-phase resolve: which of the group's four spheres can have an acceptable root for this ray
+// (bit k = sphere g + k).  Same discriminant arithmetic as resolve_group; the roots themselves are evaluated later.
+RT_DEV uint32_t group_root_mask(const float4* __restrict__ tab, uint32_t g, V3 o, V3 d, float a) {
+    const float4 S0 = tab[g], S1 = tab[g + 1], S2 = tab[g + 2], S3 = tab[g + 3];
+    float b0, b1, b2, b3, e0, e1, e2, e3;
+#define RT_DISC(S, B, E)                                               \
+    {                                                                  \
+        const float ocx = o.x - S.x;                                   \
+        const float ocy = o.y - S.y;                                   \
+        const float ocz = o.z - S.z;                                   \
+        B = (ocx * d.x + ocy * d.y) + ocz * d.z;                       \
+        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;  \
+        E = B * B - a * cc;                                            \
+    }
+    RT_DISC(S0, b0, e0)
+    RT_DISC(S1, b1, e1)
+    RT_DISC(S2, b2, e2)
+    RT_DISC(S3, b3, e3)
+#undef RT_DISC
+    return (root_possible(e0, b0) ? 1u : 0u) | (root_possible(e1, b1) ? 2u : 0u) | (root_possible(e2, b2) ? 4u : 0u) |
+           (root_possible(e3, b3) ? 8u : 0u);
+}
+
 // cand: this lane's column of the wave's candidate list in LDS; slot stride is 64 entries.
 RT_DEV void scan_list_deferred(const float4* __restrict__ tab, const uint32_t* __restrict__ orig, uint32_t nPadded, V3 o, V3 d, float& tmin,
                                int& idx, uint16_t* cand) {
@@ -347,21 +371,53 @@ constexpr uint32_t kMfmaSlots = 10;                                    // entrie
 constexpr uint32_t kStackSlots = 24;                                    // per-lane descent stack (tree scan): 3 * levels + 1 needed
 constexpr uint32_t kWaveListBytes = 64 * 2 * kMfmaSlots * 2 + 128 * 2;  // lists + counts = 3840 B per wave
 constexpr uint32_t kWaveCandBytes = kWaveListBytes + 64 * kStackSlots * 2;  // + stack = 6912 B per wave
-constexpr float kMarginRel = 2048.f * 5.9604645e-8f;                   // K * eps, K = 2048 (host uses the same K)
+constexpr float kMarginK = 4096.f;                                      // K of the filter margin (host uses the same K)
+constexpr float kMarginRel = kMarginK * 5.9604645e-8f;                 // K * eps
+constexpr uint32_t kOpsPerTile = 8 * 64;                                // dwords of the group operand image per 32-group tile
 
-// Group operand image for the filter, built once per workgroup: ops[tile][4][64] floats.
+// Split-bf16 operands.  An f32 value v is carried as h + l with h = bf16(v) and l = bf16(v - h) (both round to
+// nearest even; v - h is exact), so |v - (h + l)| <= 2^-18 |v|, and a product x*y becomes the four exact bf16 products
+// xh*yh + xh*yl + xl*yh + xl*yl accumulated in f32 by the matrix core.  One v_mfma_f32_32x32x16_bf16 (K = 16) therefore
+// evaluates a K = 4 inner product of f32-like operands: lane l supplies the two values k = 2(l>>5), 2(l>>5)+1 of its
+// row / column, each as four K-slots.  Group side (A): (yh, yh, yl, yl); ray side (B): (xh, xl, xh, xl).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+RT_DEV uint32_t bf16_pair_bits(float lo16, float hi16) {  // bf16(lo16) | bf16(hi16) << 16, round to nearest even
+    const f32x2 v = {lo16, hi16};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+// (h | h << 16) and (l | l << 16) of v: the group-side slot pairs
+RT_DEV void split_group_value(float v, uint32_t& hh, uint32_t& ll) {
+    hh = bf16_pair_bits(v, v);
+    const float rem = v - __uint_as_float(hh & 0xffff0000u);
+    ll = bf16_pair_bits(rem, rem);
+}
+// (h | l << 16) of v: the ray-side slot pair (used twice)
+RT_DEV uint32_t split_ray_value(float v) {
+    const uint32_t hh = bf16_pair_bits(v, v);
+    const float rem = v - __uint_as_float(hh & 0xffff0000u);
+    return bf16_pair_bits(v, rem);
+}
+
+// Group operand image for the filter, built once per workgroup: ops[tile][8][64] dwords; lane l of tile t holds
+// row t*32 + (l&31): dwords 0-3 = the b chain's two values (-Cx,-Cy | -Cz,1 for l>>5 = 0 | 1) as (hh, ll) pairs,
+// dwords 4-7 = the a*cc chain's (Cx,Cy | Cz,W).
 RT_DEV void build_mfma_operands(const float4* __restrict__ bounds, uint32_t nGroups, uint32_t nTiles, float* __restrict__ ops, uint32_t tid,
                                 uint32_t nthreads) {
+    uint32_t* img = reinterpret_cast<uint32_t*>(ops);
     for (uint32_t e = tid; e < nTiles * 64; e += nthreads) {
         const uint32_t t = e >> 6, l = e & 63, h = l >> 5;
         const uint32_t gi = t * 32 + (l & 31);
         float4 B = make_float4(0.f, 0.f, 0.f, 1e30f);  // padding rows: a*cc~ = +huge => F < 0, never recorded
         if (gi < nGroups) B = bounds[gi];  // bounds = the TOP level of the tree
-        float* o = ops + (size_t)t * 256 + l;
-        o[0] = h == 0 ? -B.x : -B.y;
-        o[64] = h == 0 ? -B.z : 1.f;
-        o[128] = h == 0 ? B.x : B.y;
-        o[192] = h == 0 ? B.z : B.w;
+        uint32_t* o = img + (size_t)t * kOpsPerTile + l;
+        split_group_value(h == 0 ? -B.x : -B.z, o[0], o[64]);
+        split_group_value(h == 0 ? -B.y : 1.f, o[128], o[192]);
+        split_group_value(h == 0 ? B.x : B.z, o[256], o[320]);
+        split_group_value(h == 0 ? B.y : B.w, o[384], o[448]);
     }
 }
 
@@ -412,42 +468,53 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __res
     const float oo = dot3(o, o);
     const float cr = live ? (a * oo) * (1.f - 2.f * kMarginRel) : 1e30f;
     const float bt = 1e-4f * __builtin_sqrtf(a) * (__builtin_sqrtf(oo) + boundNorm);
-    // the other half-wave's ray (lane ^ 32)
-    const float pdx = __shfl_xor(d.x, 32), pdy = __shfl_xor(d.y, 32), pdz = __shfl_xor(d.z, 32), pdO = __shfl_xor(dO, 32);
-    const float pgx = __shfl_xor(gx, 32), pgy = __shfl_xor(gy, 32), pgz = __shfl_xor(gz, 32), pa = __shfl_xor(a, 32);
-    const float pcr = __shfl_xor(cr, 32), pbt = __shfl_xor(bt, 32);
-    const bool lo = half == 0u;
-    // B operands: tile 0 = rays 0..31 (owner lanes 0..31), tile 1 = rays 32..63 (owner lanes 32..63)
-    const float bb00 = lo ? d.x : pdy, bb01 = lo ? d.z : pdO;  // tile 0: k = 0,2 from the owner, k = 1,3 from lane-32
-    const float bb10 = lo ? pdx : d.y, bb11 = lo ? pdz : dO;   // tile 1
-    const float bg00 = lo ? gx : pgy, bg01 = lo ? gz : pa;
-    const float bg10 = lo ? pgx : gy, bg11 = lo ? pgz : a;
-    const float cr0 = lo ? cr : pcr, cr1 = lo ? pcr : cr;
-    const float bt0 = lo ? bt : pbt, bt1 = lo ? pbt : bt;
+    // ray-side operands: values (k = 0,1 | 2,3) of the b chain [dx, dy | dz, d.o] and of the a*cc chain [gx, gy | gz, a].
+    // Tile 0 (rays of lanes 0-31) takes k = 0,1 from the owner and k = 2,3 from lane+32; tile 1 the other way round:
+    // v_permlane32_swap exchanges exactly those halves (upper half of the first register <-> lower half of the second).
+    uint32_t b01x = split_ray_value(d.x), b01y = split_ray_value(d.y), b23x = split_ray_value(d.z), b23y = split_ray_value(dO);
+    uint32_t g01x = split_ray_value(gx), g01y = split_ray_value(gy), g23x = split_ray_value(gz), g23y = split_ray_value(a);
+    uint32_t cr0 = __float_as_uint(cr), cr1 = cr0, bt0 = __float_as_uint(bt), bt1 = bt0;
+#define RT_SWAP32(A, B)                                                        \
+    {                                                                          \
+        const auto r_ = __builtin_amdgcn_permlane32_swap((A), (B), false, false); \
+        (A) = r_[0];                                                           \
+        (B) = r_[1];                                                           \
+    }
+    RT_SWAP32(b01x, b23x)  // now b01* = tile 0's operand, b23* = tile 1's
+    RT_SWAP32(b01y, b23y)
+    RT_SWAP32(g01x, g23x)
+    RT_SWAP32(g01y, g23y)
+    RT_SWAP32(cr0, cr1)  // per-ray scalars: cr0/bt0 belong to the ray of column lane&31 in tile 0, cr1/bt1 in tile 1
+    RT_SWAP32(bt0, bt1)
+#undef RT_SWAP32
+    const bf16x8 Bb0 = __builtin_bit_cast(bf16x8, (u32x4){b01x, b01x, b01y, b01y});
+    const bf16x8 Bb1 = __builtin_bit_cast(bf16x8, (u32x4){b23x, b23x, b23y, b23y});
+    const bf16x8 Bg0 = __builtin_bit_cast(bf16x8, (u32x4){g01x, g01x, g01y, g01y});
+    const bf16x8 Bg1 = __builtin_bit_cast(bf16x8, (u32x4){g23x, g23x, g23y, g23y});
+    const float crT0 = __uint_as_float(cr0), crT1 = __uint_as_float(cr1);
+    const float btT0 = __uint_as_float(bt0), btT1 = __uint_as_float(bt1);
     uint16_t* lists = waveCand;
     uint16_t* counts = waveCand + 64 * 2 * kMfmaSlots;
     uint16_t* list0 = lists + ((col * 2u + half) * kMfmaSlots);
     uint16_t* list1 = lists + (((col + 32u) * 2u + half) * kMfmaSlots);
     uint32_t cnt0 = 0, cnt1 = 0;
     RT_STAMP(tf0);
+    const uint32_t* opsImg = reinterpret_cast<const uint32_t*>(ops);
     for (uint32_t s = 0; s < nTiles; ++s) {
-        const float* op = ops + (size_t)s * 256 + lane;
-        const float ab1 = op[0], ab2 = op[64], ag1 = op[128], ag2 = op[192];
+        const uint32_t* op = opsImg + (size_t)s * kOpsPerTile + lane;
+        const bf16x8 Ab = __builtin_bit_cast(bf16x8, (u32x4){op[0], op[64], op[128], op[192]});
+        const bf16x8 Ag = __builtin_bit_cast(bf16x8, (u32x4){op[256], op[320], op[384], op[448]});
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const uint32_t rowBase = 32u * s + 4u * half;
         {   // ray tile 0 (rays 0..31)
-            f32x16 Tb = __builtin_amdgcn_mfma_f32_32x32x2f32(ab1, bb00, zero, 0, 0, 0);
-            f32x16 Tg = __builtin_amdgcn_mfma_f32_32x32x2f32(ag1, bg00, zero, 0, 0, 0);
-            Tb = __builtin_amdgcn_mfma_f32_32x32x2f32(ab2, bb01, Tb, 0, 0, 0);
-            Tg = __builtin_amdgcn_mfma_f32_32x32x2f32(ag2, bg01, Tg, 0, 0, 0);
-            mfma_post(Tb, Tg, cr0, bt0, list0, cnt0, rowBase);
+            const f32x16 Tb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ab, Bb0, zero, 0, 0, 0);
+            const f32x16 Tg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ag, Bg0, zero, 0, 0, 0);
+            mfma_post(Tb, Tg, crT0, btT0, list0, cnt0, rowBase);
         }
         {   // ray tile 1 (rays 32..63)
-            f32x16 Tb = __builtin_amdgcn_mfma_f32_32x32x2f32(ab1, bb10, zero, 0, 0, 0);
-            f32x16 Tg = __builtin_amdgcn_mfma_f32_32x32x2f32(ag1, bg10, zero, 0, 0, 0);
-            Tb = __builtin_amdgcn_mfma_f32_32x32x2f32(ab2, bb11, Tb, 0, 0, 0);
-            Tg = __builtin_amdgcn_mfma_f32_32x32x2f32(ag2, bg11, Tg, 0, 0, 0);
-            mfma_post(Tb, Tg, cr1, bt1, list1, cnt1, rowBase);
+            const f32x16 Tb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ab, Bb1, zero, 0, 0, 0);
+            const f32x16 Tg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ag, Bg1, zero, 0, 0, 0);
+            mfma_post(Tb, Tg, crT1, btT1, list1, cnt1, rowBase);
         }
     }
     RT_STAMP(tf1);
@@ -463,13 +530,69 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __res
     const uint32_t tot = c0 + c1;
     const uint16_t* mine = lists + lane * 2u * kMfmaSlots;
     if (!kTree) {
-        // flat: the top level IS the groups
+        // flat: the top level IS the groups.  Two phases, so that the expensive root code (sqrt + two divides) runs
+        // max-over-lanes(roots per ray) times per scan instead of once or twice per group iteration:
+        //  A. discriminants of every recorded group; a group with a possible root is written back IN PLACE over the
+        //     already consumed part of the lane's own list as gid << 4 | mask (write cursor <= read cursor);
+        //  B. every lane walks its compacted entries and evaluates one candidate sphere per iteration, recomputing b and
+        //     disc from the same inputs (same operations => same bits as phase A and as the reference).
+        // The closest-hit update is order independent (smaller t, then lower original index).  A ray whose sub-list
+        // overflowed resolves every group immediately instead (rare).
+        uint16_t* own = lists + lane * 2u * kMfmaSlots;
+        uint32_t nq = 0;
+        RT_STAMP(ta0);
         for (uint32_t it = 0; __ballot(it < tot) != 0ull; ++it) {
+#ifdef RT_STAMPS
+            dbg[6] += 1;
+#endif
             if (it < tot) {
-                const uint32_t gid = overflow ? it : (it < c0 ? mine[it] : mine[kMfmaSlots + (it - c0)]);
-                resolve_group(tab, orig, 4u * gid, o, d, a, tmin, idx);
+                if (__builtin_expect(overflow, 0)) {
+                    resolve_group(tab, orig, 4u * it, o, d, a, tmin, idx);
+                } else {
+                    const uint32_t gid = it < c0 ? own[it] : own[kMfmaSlots + (it - c0)];
+                    const uint32_t m = group_root_mask(tab, 4u * gid, o, d, a);
+                    if (m != 0u) {
+                        own[nq < c0 ? nq : kMfmaSlots + (nq - c0)] = (uint16_t)(gid << 4 | m);
+                        ++nq;
+                    }
+                }
             }
         }
+        uint32_t rdPos = 0, cur = 0;
+        RT_STAMP(ta1);
+        RT_ACC(dbg[4], ta0, ta1);
+        for (;;) {
+#ifdef RT_STAMPS
+            dbg[7] += 1;
+#endif
+            if (cur == 0u && rdPos < nq) {
+                cur = own[rdPos < c0 ? rdPos : kMfmaSlots + (rdPos - c0)];
+                ++rdPos;
+            }
+            if (__ballot(cur != 0u) == 0ull) break;
+            if (cur != 0u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(cur & 15u);
+                const uint32_t cand = 4u * (cur >> 4) + k;
+                cur &= cur - 1u;              // clear the lowest mask bit ...
+                if ((cur & 15u) == 0u) cur = 0u;  // ... and drop the entry once its mask is empty
+                const float4 S = tab[cand];
+                const float ocx = o.x - S.x;
+                const float ocy = o.y - S.y;
+                const float ocz = o.z - S.z;
+                const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
+                const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;
+                const float e = b * b - a * cc;
+                const float sq = __builtin_sqrtf(e);
+                float t = (-b - sq) / a;               // ray-tracing.cpp:56
+                if (!(t > 0.001f)) t = (-b + sq) / a;  // :69
+                if (t > 0.001f && (t < tmin || (t == tmin && idx >= 0 && orig[cand] < orig[idx]))) {
+                    tmin = t;
+                    idx = (int)cand;
+                }
+            }
+        }
+        RT_STAMP(ta2);
+        RT_ACC(dbg[5], ta1, ta2);
     } else {
         // descent: per-lane depth-first walk of the 4-ary bounds hierarchy below each surviving top node.  A node id
         // is level << 13 | index.  Internal steps run while ANY lane has an internal node on top of its stack; exact
@@ -788,7 +911,7 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
             build_mfma_operands(p.tree + p.level_off[topLevel], nTop, nTiles, ldsOps, threadIdx.x, blockDim.x);
             mfmaOps = ldsOps;
             if (p.sg_enabled && p.sg_in_lds) {  // shadow index after the operand image
-                uint16_t* g = reinterpret_cast<uint16_t*>(ldsOps + (size_t)nTiles * 256);
+                uint16_t* g = reinterpret_cast<uint16_t*>(ldsOps + (size_t)nTiles * kOpsPerTile);
                 const uint32_t nc = p.sg_nx * p.sg_ny + 1u;
                 for (uint32_t k = threadIdx.x; k < nc; k += blockDim.x) g[k] = p.sg_cell_start[k];
                 for (uint32_t k = threadIdx.x; k < p.sg_nentries; k += blockDim.x) g[nc + k] = p.sg_entries[k];
@@ -809,7 +932,7 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
         build_mfma_operands(p.tree + p.level_off[topLevel], nTop, nTiles, ldsOps, threadIdx.x, blockDim.x);
         mfmaOps = ldsOps;
         if (p.tree_in_lds) {
-            float4* ldsTree = reinterpret_cast<float4*>(ldsOps + (size_t)nTiles * 256);
+            float4* ldsTree = reinterpret_cast<float4*>(ldsOps + (size_t)nTiles * kOpsPerTile);
             const uint32_t nNodes = p.level_off[topLevel] + nTop;
             for (uint32_t k = threadIdx.x; k < nNodes; k += blockDim.x) ldsTree[k] = p.tree[k];
             treeTab = ldsTree;
@@ -836,10 +959,10 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
     uint32_t blkNext = 0, blkEnd = 0;
     bool queueEmpty = false;
 
-    unsigned long long dbgScan[4] = {0, 0, 0, 0};
+    unsigned long long dbgScan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)dbgScan;
 #ifdef RT_STAMPS
-    unsigned long long cyRefill = 0, cyScan = 0, cyTrans = 0, cyIters = 0;
+    unsigned long long cyRefill = 0, cyScan = 0, cyTrans = 0, cyIters = 0, cyHit[3] = {0, 0, 0};
 #endif
     for (;;) {
         RT_STAMP(ts0);
@@ -923,13 +1046,20 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
                 const V3 pos = tmin * rd + ro;          // XMVectorMultiplyAdd(t, dir, origin), ray-tracing.cpp:57
                 const V3 nrm = (pos - center) / radius;  // ray-tracing.cpp:58
                 V3 atten, local, localOcc, tex;
+                RT_STAMP(th0);
                 const bool scattered = scatter_only(m, rd, nrm, draws, atten, nextDir, tex);  // Scatter first: it draws (spheres-app.cpp:246)
+                RT_STAMP(th1);
                 const bool cont = (depth < p.max_depth) && scattered;  // spheres-app.cpp:247
                 const bool useIndex = p.sg_enabled && dot3(pos, pos) <= p.sg_p0sq;
                 bool occluded = false;
                 if (useIndex) occluded = shadow_query(p, scanTab, sgCell, sgEntries, sgGlobal, pos, sunDir, aSun);
+                RT_STAMP(th2);
                 // the Blinn-Phong value (two normalisations, two pows) is only needed when the sun is visible or unknown
                 shade_value(p, m, tex, pos, nrm, !occluded, local, localOcc);
+                RT_STAMP(th3);
+                RT_ACC(cyHit[0], th0, th1);
+                RT_ACC(cyHit[1], th1, th2);
+                RT_ACC(cyHit[2], th2, th3);
                 if (useIndex) {
                     // shadow ray answered by the exact footprint index: no second scan for this hit
                     ++nTrav;  // the shadow ray still counts as a traversal of the scene (matches the oracle's counter)
@@ -1007,6 +1137,13 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
         atomicAdd(&g_dbg[4], dbgScan[0]);
         atomicAdd(&g_dbg[5], dbgScan[1]);
         atomicAdd(&g_dbg[7], dbgScan[3]);
+        atomicAdd(&g_dbg[8], dbgScan[4]);
+        atomicAdd(&g_dbg[9], dbgScan[5]);
+        atomicAdd(&g_dbg[10], dbgScan[6]);
+        atomicAdd(&g_dbg[11], dbgScan[7]);
+        atomicAdd(&g_dbg[12], cyHit[0]);
+        atomicAdd(&g_dbg[13], cyHit[1]);
+        atomicAdd(&g_dbg[14], cyHit[2]);
 #endif
     }
 }

@@ -126,7 +126,7 @@ def test_clustered_layout_is_a_partition_with_enclosing_bounds(built, oracle, na
     assert sorted(members.tolist()) == list(range(sc.n))
     c = np.stack([sc.spheres["cx"], sc.spheres["cy"], sc.spheres["cz"]], 1).astype(np.float64)
     r = sc.spheres["r"].astype(np.float64)
-    keps = 2048 * 2.0 ** -24
+    keps = 4096 * 2.0 ** -24  # rt_kernels.h kMarginK
     for g in range(orig.shape[0]):
         ids = orig[g][orig[g] != 0xFFFFFFFF]
         if len(ids) == 0:
