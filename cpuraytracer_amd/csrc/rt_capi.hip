@@ -958,12 +958,12 @@ int rt_unit_layout(const rt_sphere* spheres, uint32_t n, uint32_t cap_groups, ui
 
 #ifdef RT_STAMPS
 // Diagnostic build only: read and clear the section clocks (see rt_kernels.h g_dbg).
-int rt_debug_stamps(rt_ctx* ctx, unsigned long long out[16]) {
+int rt_debug_stamps(rt_ctx* ctx, unsigned long long out[20]) {
     if (!ctx || !out) return Fail(RT_ERR_INVALID_ARG, "rt_debug_stamps: invalid argument");
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipStreamSynchronize(ctx->stream));
-    RT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(rtd::g_dbg), 16 * sizeof(unsigned long long)));
-    unsigned long long z[16] = {0};
+    RT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(rtd::g_dbg), 20 * sizeof(unsigned long long)));
+    unsigned long long z[20] = {0};
     RT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_dbg), z, sizeof(z)));
     return RT_OK;
 }

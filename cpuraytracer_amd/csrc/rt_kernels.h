@@ -41,7 +41,7 @@ namespace rtd {
 // Diagnostic build only (-DRT_STAMPS): per-section shader-clock sums go to g_dbg[], which no kernel reads.
 // The shipped library is built without it.
 #ifdef RT_STAMPS
-static __device__ unsigned long long g_dbg[16];  // refill, scan, transitions, iterations, filter, resolve, resolve items, max items,
+static __device__ unsigned long long g_dbg[20];  // refill, scan, transitions, iterations, filter, resolve, resolve items, max items,
                                                  // phase A cycles, phase B cycles, A iterations, B iterations, scatter, shadow query, shade, -
 RT_DEV unsigned long long rt_stamp() {
     unsigned long long t;
@@ -710,7 +710,12 @@ RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V
     tex = eval_texture(m, uvx, uvy);
     bool scattered = false;
     atten = v3(1.f, 1.f, 1.f);
-    outDir = v3(0.f, 0.f, 0.f);
+    // Every material's scattered direction is XMVector3Normalize of something, and three of the five cases normalise
+    // XMVector3Reflect(ray.direction, hit.normal): the branches below only choose the un-normalised vector, and one
+    // reflect / one normalise run for all lanes of the wave afterwards (same function of the same inputs: same bits).
+    V3 raw = v3(0.f, 0.f, 0.f);
+    const V3 mirror = reflect3(rd, nrm);
+    const float ndv = dot3(-rd, nrm);  // material.cpp:22,74
 
     if (m.type == RT_MAT_DIELECTRIC_TRANSPARENT) {  // material.cpp:111-164
         const float dn = dot3(rd, nrm);
@@ -729,28 +734,25 @@ RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V
         const bool canRefract = (refr.x != 0.f) || (refr.y != 0.f) || (refr.z != 0.f);
         const float prob = canRefract ? fresnel_term(cosI, m.ior) : 1.f;
         const float u = draws.next();
-        if (prob > u) outDir = normalize3(reflect3(rd, nrm));
-        else outDir = normalize3(refr);
+        raw = prob > u ? mirror : refr;
         scattered = true;
     } else if (m.type == RT_MAT_METAL) {  // material.cpp:72-103
-        const float ndv = dot3(-rd, nrm);
         if (ndv > 0.f) {
             // The 4-lane coin (XMVectorGreaterR + AnyTrue) is always true: lane w of f0 is the
             // colour's alpha = 1, so R.w = 1 > u.  The draw is still consumed (material.cpp:82).
             (void)draws.next();
             atten = tex;
-            outDir = normalize3(reflect3(rd, nrm));
+            raw = mirror;
             scattered = true;
         }
     } else if (m.type == RT_MAT_DIELECTRIC_OPAQUE) {  // material.cpp:20-65
-        const float ndv = dot3(-rd, nrm);
         if (ndv > 0.f) {
             const float nDotV = sat1(ndv);
             const float refl = 0.04f + (1.f - 0.04f) * rt_powf(1.f - nDotV, 5.f);
             const float u = draws.next();
             if (refl > u) {
                 atten = v3(1.f, 1.f, 1.f);
-                outDir = normalize3(reflect3(rd, nrm));
+                raw = mirror;
             } else {
                 atten = tex;
                 const float u1 = draws.next();  // HaltonSampleHemisphere's two dimensions
@@ -764,13 +766,13 @@ RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V
                 const V3 up = __builtin_fabsf(nrm.x) < 0.5f ? v3(1.f, 0.f, 0.f) : v3(0.f, 1.f, 0.f);
                 const V3 b1 = cross3(up, b3);
                 const V3 b2 = cross3(b3, b1);
-                const V3 sd = (hx * b1 + hy * b2) + hz * b3;
-                outDir = normalize3(sd);
+                raw = (hx * b1 + hy * b2) + hz * b3;
             }
             scattered = true;
         }
     }
-
+    outDir = normalize3(raw);
+    if (!scattered) outDir = v3(0.f, 0.f, 0.f);
     return scattered;
 }
 
@@ -962,7 +964,7 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
     unsigned long long dbgScan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)dbgScan;
 #ifdef RT_STAMPS
-    unsigned long long cyRefill = 0, cyScan = 0, cyTrans = 0, cyIters = 0, cyHit[3] = {0, 0, 0};
+    unsigned long long cyRefill = 0, cyScan = 0, cyTrans = 0, cyIters = 0, cyHit[6] = {0, 0, 0, 0, 0, 0};
 #endif
     for (;;) {
         RT_STAMP(ts0);
@@ -1030,6 +1032,9 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
         RT_STAMP(ts2);
         // ------------------------------------------------ state transitions
         bool finished = false;
+#ifdef RT_STAMPS
+        unsigned long long thA = 0, thB = 0;
+#endif
         if (state == kNeedClosest) {
             ++nSeg;
             if (idx < 0) {
@@ -1057,6 +1062,10 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
                 // the Blinn-Phong value (two normalisations, two pows) is only needed when the sun is visible or unknown
                 shade_value(p, m, tex, pos, nrm, !occluded, local, localOcc);
                 RT_STAMP(th3);
+#ifdef RT_STAMPS
+                thA = th0;
+                thB = th3;
+#endif
                 RT_ACC(cyHit[0], th0, th1);
                 RT_ACC(cyHit[1], th1, th2);
                 RT_ACC(cyHit[2], th2, th3);
@@ -1105,6 +1114,13 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
             state = kIdle;
         }
         RT_STAMP(ts3);
+#ifdef RT_STAMPS
+        if (thA != 0) {  // lanes that processed a hit this iteration (uniform enough: lane 0 reports)
+            cyHit[3] += thA - ts2;
+            cyHit[4] += ts3 - thB;
+            cyHit[5] += 1;
+        }
+#endif
         RT_ACC(cyRefill, ts0, ts1);
         RT_ACC(cyScan, ts1, ts2);
         RT_ACC(cyTrans, ts2, ts3);
@@ -1144,6 +1160,9 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
         atomicAdd(&g_dbg[12], cyHit[0]);
         atomicAdd(&g_dbg[13], cyHit[1]);
         atomicAdd(&g_dbg[14], cyHit[2]);
+        atomicAdd(&g_dbg[15], cyHit[3]);
+        atomicAdd(&g_dbg[16], cyHit[4]);
+        atomicAdd(&g_dbg[17], cyHit[5]);
 #endif
     }
 }

@@ -8,7 +8,7 @@ from cpuraytracer_amd import HipRenderer, scenes
 r = HipRenderer(0)
 r.upload(scenes.build_scene("cover", 1, 1200, 800))
 L = _capi.load()
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 20)()
 L.rt_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 r.render(1200, 800, 1, 17, 50, 1)
 L.rt_debug_stamps(r._h, out)
@@ -22,4 +22,4 @@ print(json.dumps({"wave_iterations": v[3], "cycles_per_iteration": tot / v[3], "
                   "lanes_live_per_iteration": st.traversals / v[3],
                   "phaseA_cycles_per_iteration": v[8] / v[3], "phaseB_cycles_per_iteration": v[9] / v[3],
                   "phaseA_steps_per_iteration": v[10] / v[3], "phaseB_steps_per_iteration": v[11] / v[3],
-                  "hit_scatter_cycles": v[12] / v[3], "hit_shadow_query_cycles": v[13] / v[3], "hit_shade_cycles": v[14] / v[3], "ms_trace_stamped_build": st.ms_render}))
+                  "hit_scatter_cycles": v[12] / v[3], "hit_shadow_query_cycles": v[13] / v[3], "hit_shade_cycles": v[14] / v[3], "lane0_hit_iterations": v[17], "hit_pre_cycles_when_lane0_hits": v[15] / max(1, v[17]), "hit_post_cycles_when_lane0_hits": v[16] / max(1, v[17]), "ms_trace_stamped_build": st.ms_render}))
