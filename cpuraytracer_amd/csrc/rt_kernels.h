@@ -842,17 +842,48 @@ RT_DEV bool sphere_any_hit(const float4 S, V3 o, V3 d, float a) {
     return false;
 }
 
+// Two phases, like the closest-hit resolve: first the discriminants of every listed sphere (cheap, uniform), keeping
+// up to four spheres whose roots are possible in a register queue; then roots (sqrt + divides) only for those, until
+// one occludes.  root_possible() is exact, so the answer is the reference's any-hit over the same spheres.
 RT_DEV bool shadow_query(const TraceParams& p, const float4* __restrict__ tab, const uint16_t* __restrict__ cellStart,
                          const uint16_t* __restrict__ entries, const uint16_t* __restrict__ glob, V3 pos, V3 L, float aL) {
     bool occluded = false;
-    for (uint32_t k = 0; k < p.sg_nglobal && !occluded; ++k) occluded = sphere_any_hit(tab[glob[k]], pos, L, aL);
+    unsigned long long queue = 0ull;
+    uint32_t nq = 0;
+#define RT_CONSIDER(ID)                                                              \
+    {                                                                                \
+        const uint32_t id_ = (ID);                                                   \
+        const float4 S = tab[id_];                                                   \
+        const float ocx = pos.x - S.x;                                               \
+        const float ocy = pos.y - S.y;                                               \
+        const float ocz = pos.z - S.z;                                               \
+        const float b = (ocx * L.x + ocy * L.y) + ocz * L.z;                         \
+        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;                \
+        const float disc = b * b - aL * cc;                                          \
+        if (root_possible(disc, b)) {                                                \
+            if (nq < 4u) {                                                           \
+                queue = (queue << 16) | (unsigned long long)id_;                     \
+                ++nq;                                                                \
+            } else {                                                                 \
+                occluded = occluded || sphere_any_hit(S, pos, L, aL); /* queue full (rare): evaluate now */ \
+            }                                                                        \
+        }                                                                            \
+    }
+    for (uint32_t k = 0; k < p.sg_nglobal; ++k) RT_CONSIDER(glob[k])
     const float u = dot3(pos, v3(p.sg_e1[0], p.sg_e1[1], p.sg_e1[2]));
     const float v = dot3(pos, v3(p.sg_e2[0], p.sg_e2[1], p.sg_e2[2]));
     const float fx = (u - p.sg_u0) * p.sg_inv_cell, fy = (v - p.sg_v0) * p.sg_inv_cell;
-    if (!occluded && fx >= 0.f && fy >= 0.f && fx < (float)p.sg_nx && fy < (float)p.sg_ny) {
+    if (fx >= 0.f && fy >= 0.f && fx < (float)p.sg_nx && fy < (float)p.sg_ny) {
         const uint32_t c = (uint32_t)fy * p.sg_nx + (uint32_t)fx;
         const uint32_t e1 = cellStart[c + 1];
-        for (uint32_t e = cellStart[c]; e < e1 && !occluded; ++e) occluded = sphere_any_hit(tab[entries[e]], pos, L, aL);
+        for (uint32_t e = cellStart[c]; e < e1; ++e) RT_CONSIDER(entries[e])
+    }
+#undef RT_CONSIDER
+    while (nq > 0u && !occluded) {
+        const uint32_t id = (uint32_t)(queue & 0xffffull);
+        queue >>= 16;
+        --nq;
+        occluded = sphere_any_hit(tab[id], pos, L, aL);
     }
     return occluded;
 }
