@@ -357,7 +357,7 @@ static void BuildShadowGrid(const rt_sphere* sp, const SceneLayout& L, const flo
 static size_t LdsBytesFor(uint32_t n, uint32_t nPadded, bool mats) {
     return (size_t)nPadded * (16 + 4) + (mats ? (size_t)n * 48 : 0) + (size_t)((n + 3) / 4) * 16;
 }
-static size_t MfmaOpsBytesFor(uint32_t nGroups) { return (size_t)((nGroups + 31u) / 32u) * rtd::kOpsPerTile * 4; }
+static size_t MfmaOpsBytesFor(uint32_t nGroups) { return (size_t)rtd::mfma_tiles_for(nGroups) * rtd::kOpsPerTile * 4; }
 
 // Launch the megakernel over total paths described by tp.
 static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {

@@ -367,10 +367,10 @@ RT_DEV void scan_list_deferred(const float4* __restrict__ tab, const uint32_t* _
 // with its own sub-list and register counter (no atomics).  A sub-list that overflows makes its ray
 // fall back to resolving every group (rare; still exact).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr uint32_t kMfmaSlots = 10;                                    // entries per (ray, half) sub-list
+constexpr uint32_t kMfmaSlots = 20;                                    // phase-A output entries per ray (gid << 4 | root mask)
 constexpr uint32_t kStackSlots = 24;                                    // per-lane descent stack (tree scan): 3 * levels + 1 needed
-constexpr uint32_t kWaveListBytes = 64 * 2 * kMfmaSlots * 2 + 128 * 2;  // lists + counts = 3840 B per wave
-constexpr uint32_t kWaveCandBytes = kWaveListBytes + 64 * kStackSlots * 2;  // + stack = 6912 B per wave
+constexpr uint32_t kWaveListBytes = 64 * kMfmaSlots * 2;                // phase-A lists = 2560 B per wave
+constexpr uint32_t kWaveCandBytes = kWaveListBytes + 64 * kStackSlots * 2;  // + stack = 5632 B per wave
 constexpr float kMarginK = 4096.f;                                      // K of the filter margin (host uses the same K)
 constexpr float kMarginRel = kMarginK * 5.9604645e-8f;                 // K * eps
 constexpr uint32_t kOpsPerTile = 8 * 64;                                // dwords of the group operand image per 32-group tile
@@ -403,15 +403,18 @@ RT_DEV uint32_t split_ray_value(float v) {
 }
 
 // Group operand image for the filter, built once per workgroup: ops[tile][8][64] dwords; lane l of tile t holds
-// row t*32 + (l&31): dwords 0-3 = the b chain's two values (-Cx,-Cy | -Cz,1 for l>>5 = 0 | 1) as (hh, ll) pairs,
-// dwords 4-7 = the a*cc chain's (Cx,Cy | Cz,W).
+// matrix row R = l&31: dwords 0-3 = the b chain's two values (-Cx,-Cy | -Cz,1 for l>>5 = 0 | 1) as (hh, ll) pairs,
+// dwords 4-7 = the a*cc chain's (Cx,Cy | Cz,W).  Rows are PERMUTED so that the candidate bitmaps decode with two
+// operations: output element e (0..15) of the lane in half h is matrix row (e&3) + 8(e>>2) + 4h, and that row holds
+// group 32 t + 16 h + e.  The image always has an even number of tiles (bitmap words cover two tiles).
+RT_DEV uint32_t mfma_tiles_for(uint32_t nTop) { return (((nTop + 31u) / 32u) + 1u) & ~1u; }
 RT_DEV void build_mfma_operands(const float4* __restrict__ bounds, uint32_t nGroups, uint32_t nTiles, float* __restrict__ ops, uint32_t tid,
                                 uint32_t nthreads) {
     uint32_t* img = reinterpret_cast<uint32_t*>(ops);
     for (uint32_t e = tid; e < nTiles * 64; e += nthreads) {
-        const uint32_t t = e >> 6, l = e & 63, h = l >> 5;
-        const uint32_t gi = t * 32 + (l & 31);
-        float4 B = make_float4(0.f, 0.f, 0.f, 1e30f);  // padding rows: a*cc~ = +huge => F < 0, never recorded
+        const uint32_t t = e >> 6, l = e & 63, h = l >> 5, R = l & 31u;
+        const uint32_t gi = t * 32 + 16u * ((R >> 2) & 1u) + (R & 3u) + 4u * (R >> 3);
+        float4 B = make_float4(0.f, 0.f, 0.f, 1e30f);  // padding rows: a*cc~ = +huge => F < 0, never a candidate
         if (gi < nGroups) B = bounds[gi];  // bounds = the TOP level of the tree
         uint32_t* o = img + (size_t)t * kOpsPerTile + l;
         split_group_value(h == 0 ? -B.x : -B.z, o[0], o[64]);
@@ -421,35 +424,37 @@ RT_DEV void build_mfma_operands(const float4* __restrict__ bounds, uint32_t nGro
     }
 }
 
-// Record the groups of this lane's 16 rows that the ray may hit: filter value F = b~^2 - t >= 0 (t = a*cc~ - M)
-// and NOT surely behind the origin.  "Behind" = the origin is outside the inflated bound (t > 0, which already
+// Filter decision for this lane's 16 rows of one tile: the ray may hit the group unless F = b~^2 - t < 0 (t = a*cc~ - M)
+// or the group is surely behind the origin.  "Behind" = the origin is outside the inflated bound (t > 0, which already
 // includes the margin) and the centre is behind it by more than the rounding of b~ (b~ > bthr, bthr =
-// 1e-4 sqrt(a) (|o| + max(|C|+R)) >= 185x the error bound 9 eps sqrt(a)(|o|+|C|)): then every point of the bound,
-// hence of its member spheres, has t < 0 and the reference accepts no root (bias 0.001, ray-tracing.cpp:52).
-// All three conditions are sign bits; one 3-input bit operation per element forms "rejected".
-RT_DEV void mfma_post(const f32x16& Tb, const f32x16& Tg, float cray, float bthr, uint16_t* list, uint32_t& cnt, uint32_t rowBase) {
+// 1e-4 sqrt(a) (|o| + max(|C|+R)) >= 185x the error bound of b~): then every point of the bound, hence of its member
+// spheres, has t < 0 and the reference accepts no root (bias 0.001, ray-tracing.cpp:52).
+// All three conditions are sign bits: one 3-input bit operation forms "rejected", one v_alignbit appends its sign bit
+// to the lane's bitmap word (five VALU operations per (ray, group) pair, no branches, no LDS).
+RT_DEV void mfma_post(const f32x16& Tb, const f32x16& Tg, float cray, float bthr, uint32_t& rejectedBits) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        int rej[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float t = Tg[4 * g + q] + cray;
-            const float f = __builtin_fmaf(Tb[4 * g + q], Tb[4 * g + q], -t);
-            const float u = bthr - Tb[4 * g + q];  // negative <=> centre behind the origin
-            // rejected = sign(f) | (sign(u) & ~sign(t))
-            rej[q] = __float_as_int(f) | (__float_as_int(u) & ~__float_as_int(t));
-        }
-        const int all = rej[0] & rej[1] & rej[2] & rej[3];
-        if (__builtin_expect(all >= 0, 0)) {  // some element has a clear sign bit: a candidate
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (rej[q] >= 0) {
-                    if (cnt < kMfmaSlots) list[cnt] = (uint16_t)(rowBase + 8u * (uint32_t)g + (uint32_t)q);
-                    ++cnt;  // keeps counting past the capacity: the owner then resolves every group
-                }
-            }
-        }
+    for (int e = 0; e < 16; ++e) {
+        const float t = Tg[e] + cray;
+        const float f = __builtin_fmaf(Tb[e], Tb[e], -t);
+        const float u = bthr - Tb[e];  // negative <=> centre behind the origin
+        const uint32_t rej = __float_as_uint(f) | (__float_as_uint(u) & ~__float_as_uint(t));  // sign bit = rejected
+        rejectedBits = __builtin_amdgcn_alignbit(rejectedBits, rej, 31);  // (bits << 1) | (rej >> 31)
     }
+}
+
+// One candidate of a ray's 128-bit bitmap (two 64-bit halves: the rows filtered by lanes l&31 and (l&31)+32).  Returns
+// false when none is left.  Leading-zero order; bit N (from the top) of half h is group 16 h + N + (N & 48).
+RT_DEV bool next_candidate(unsigned long long& cur, unsigned long long& nxt, uint32_t& hOff, uint32_t& gid) {
+    if (cur == 0ull) {
+        cur = nxt;
+        nxt = 0ull;
+        hOff = 16u;
+    }
+    if (cur == 0ull) return false;
+    const uint32_t N = (uint32_t)__builtin_clzll(cur);
+    cur &= ~(0x8000000000000000ull >> N);
+    gid = hOff + N + (N & 48u);
+    return true;
 }
 
 template <bool kTree>
@@ -459,7 +464,6 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __res
     const float a = dot3(d, d);
     tmin = __builtin_inff();
     idx = -1;
-    const uint32_t half = lane >> 5, col = lane & 31u;
     // per-ray operand values (filter arithmetic: any rounding, the margin covers it)
     const float dO = dot3(d, o);
     const float m2a = -2.f * a;
@@ -493,88 +497,99 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __res
     const bf16x8 Bg1 = __builtin_bit_cast(bf16x8, (u32x4){g23x, g23x, g23y, g23y});
     const float crT0 = __uint_as_float(cr0), crT1 = __uint_as_float(cr1);
     const float btT0 = __uint_as_float(bt0), btT1 = __uint_as_float(bt1);
-    uint16_t* lists = waveCand;
-    uint16_t* counts = waveCand + 64 * 2 * kMfmaSlots;
-    uint16_t* list0 = lists + ((col * 2u + half) * kMfmaSlots);
-    uint16_t* list1 = lists + (((col + 32u) * 2u + half) * kMfmaSlots);
-    uint32_t cnt0 = 0, cnt1 = 0;
     RT_STAMP(tf0);
     const uint32_t* opsImg = reinterpret_cast<const uint32_t*>(ops);
-    for (uint32_t s = 0; s < nTiles; ++s) {
-        const uint32_t* op = opsImg + (size_t)s * kOpsPerTile + lane;
-        const bf16x8 Ab = __builtin_bit_cast(bf16x8, (u32x4){op[0], op[64], op[128], op[192]});
-        const bf16x8 Ag = __builtin_bit_cast(bf16x8, (u32x4){op[256], op[320], op[384], op[448]});
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const uint32_t rowBase = 32u * s + 4u * half;
-        {   // ray tile 0 (rays 0..31)
-            const f32x16 Tb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ab, Bb0, zero, 0, 0, 0);
-            const f32x16 Tg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ag, Bg0, zero, 0, 0, 0);
-            mfma_post(Tb, Tg, crT0, btT0, list0, cnt0, rowBase);
+    // rejected-bits words: w0* = ray tile 0 (the ray of lane l&31), w1* = ray tile 1 (the ray of lane (l&31)+32);
+    // *a = tiles 0,1, *b = tiles 2,3 (all ones = nothing to resolve when the image has only two tiles)
+    uint32_t w0a = 0xffffffffu, w1a = 0xffffffffu, w0b = 0xffffffffu, w1b = 0xffffffffu;
+    for (uint32_t sp = 0; sp < nTiles; sp += 2) {
+        uint32_t r0 = 0u, r1 = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 2; ++k) {
+            const uint32_t* op = opsImg + (size_t)(sp + k) * kOpsPerTile + lane;
+            const bf16x8 Ab = __builtin_bit_cast(bf16x8, (u32x4){op[0], op[64], op[128], op[192]});
+            const bf16x8 Ag = __builtin_bit_cast(bf16x8, (u32x4){op[256], op[320], op[384], op[448]});
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            {   // ray tile 0 (rays 0..31)
+                const f32x16 Tb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ab, Bb0, zero, 0, 0, 0);
+                const f32x16 Tg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ag, Bg0, zero, 0, 0, 0);
+                mfma_post(Tb, Tg, crT0, btT0, r0);
+            }
+            {   // ray tile 1 (rays 32..63)
+                const f32x16 Tb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ab, Bb1, zero, 0, 0, 0);
+                const f32x16 Tg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ag, Bg1, zero, 0, 0, 0);
+                mfma_post(Tb, Tg, crT1, btT1, r1);
+            }
         }
-        {   // ray tile 1 (rays 32..63)
-            const f32x16 Tb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ab, Bb1, zero, 0, 0, 0);
-            const f32x16 Tg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ag, Bg1, zero, 0, 0, 0);
-            mfma_post(Tb, Tg, crT1, btT1, list1, cnt1, rowBase);
+        if (sp == 0u) {
+            w0a = r0;
+            w1a = r1;
+        } else {
+            w0b = r0;
+            w1b = r1;
         }
     }
     RT_STAMP(tf1);
-    // publish the producers' counts, then every lane works on its OWN ray's two sub-lists
-    counts[col * 2u + half] = (uint16_t)(cnt0 < 0xffffu ? cnt0 : 0xffffu);
-    counts[(col + 32u) * 2u + half] = (uint16_t)(cnt1 < 0xffffu ? cnt1 : 0xffffu);
-    uint32_t c0 = counts[lane * 2u], c1 = counts[lane * 2u + 1u];
-    const bool overflow = c0 > kMfmaSlots || c1 > kMfmaSlots;
-    if (overflow) {  // exhaustive (still exact) fallback for this ray: every top-level node
-        c0 = nTop;
-        c1 = 0;
+    // every ray has two producer lanes (l&31 filtered rows of half 0, (l&31)+32 those of half 1); after the swaps
+    // w0* holds the half-0 words and w1* the half-1 words of THIS lane's own ray
+    {
+        const auto ra = __builtin_amdgcn_permlane32_swap(w0a, w1a, false, false);
+        const auto rb = __builtin_amdgcn_permlane32_swap(w0b, w1b, false, false);
+        w0a = ra[0]; w1a = ra[1]; w0b = rb[0]; w1b = rb[1];
     }
-    const uint32_t tot = c0 + c1;
-    const uint16_t* mine = lists + lane * 2u * kMfmaSlots;
+    unsigned long long cur = ~(((unsigned long long)w0a << 32) | (unsigned long long)w0b);  // candidates of half 0
+    unsigned long long nxt = ~(((unsigned long long)w1a << 32) | (unsigned long long)w1b);  // candidates of half 1
+    uint32_t hOff = 0u;
+#ifdef RT_STAMPS
+    const uint32_t tot = (uint32_t)(__popcll(cur) + __popcll(nxt));
+#endif
     if (!kTree) {
         // flat: the top level IS the groups.  Two phases, so that the expensive root code (sqrt + two divides) runs
-        // max-over-lanes(roots per ray) times per scan instead of once or twice per group iteration:
-        //  A. discriminants of every recorded group; a group with a possible root is written back IN PLACE over the
-        //     already consumed part of the lane's own list as gid << 4 | mask (write cursor <= read cursor);
-        //  B. every lane walks its compacted entries and evaluates one candidate sphere per iteration, recomputing b and
-        //     disc from the same inputs (same operations => same bits as phase A and as the reference).
-        // The closest-hit update is order independent (smaller t, then lower original index).  A ray whose sub-list
-        // overflowed resolves every group immediately instead (rare).
-        uint16_t* own = lists + lane * 2u * kMfmaSlots;
+        // max-over-lanes(roots per ray) times per scan instead of once or twice per group step:
+        //  A. discriminants of every candidate group; a group with a possible root is appended to the lane's list in
+        //     LDS as gid << 4 | mask (a full list makes the lane evaluate that group's roots at once: rare, exact);
+        //  B. every lane walks its entries and evaluates one candidate sphere per step, recomputing b and disc from
+        //     the same inputs (same operations => same bits as phase A and as the reference).
+        // The closest-hit update is order independent (smaller t, then lower original index).
+        uint16_t* own = waveCand + lane * kMfmaSlots;
         uint32_t nq = 0;
         RT_STAMP(ta0);
-        for (uint32_t it = 0; __ballot(it < tot) != 0ull; ++it) {
+        for (;;) {
+            uint32_t gid = 0;
+            const bool has = next_candidate(cur, nxt, hOff, gid);
+            if (__ballot(has) == 0ull) break;
 #ifdef RT_STAMPS
             dbg[6] += 1;
 #endif
-            if (it < tot) {
-                if (__builtin_expect(overflow, 0)) {
-                    resolve_group(tab, orig, 4u * it, o, d, a, tmin, idx);
-                } else {
-                    const uint32_t gid = it < c0 ? own[it] : own[kMfmaSlots + (it - c0)];
-                    const uint32_t m = group_root_mask(tab, 4u * gid, o, d, a);
-                    if (m != 0u) {
-                        own[nq < c0 ? nq : kMfmaSlots + (nq - c0)] = (uint16_t)(gid << 4 | m);
+            if (has) {
+                const uint32_t m = group_root_mask(tab, 4u * gid, o, d, a);
+                if (m != 0u) {
+                    if (__builtin_expect(nq < kMfmaSlots, 1)) {
+                        own[nq] = (uint16_t)(gid << 4 | m);
                         ++nq;
+                    } else {
+                        resolve_group(tab, orig, 4u * gid, o, d, a, tmin, idx);
                     }
                 }
             }
         }
-        uint32_t rdPos = 0, cur = 0;
+        uint32_t rdPos = 0, ent = 0;
         RT_STAMP(ta1);
         RT_ACC(dbg[4], ta0, ta1);
         for (;;) {
 #ifdef RT_STAMPS
             dbg[7] += 1;
 #endif
-            if (cur == 0u && rdPos < nq) {
-                cur = own[rdPos < c0 ? rdPos : kMfmaSlots + (rdPos - c0)];
+            if (ent == 0u && rdPos < nq) {
+                ent = own[rdPos];
                 ++rdPos;
             }
-            if (__ballot(cur != 0u) == 0ull) break;
-            if (cur != 0u) {
-                const uint32_t k = (uint32_t)__builtin_ctz(cur & 15u);
-                const uint32_t cand = 4u * (cur >> 4) + k;
-                cur &= cur - 1u;              // clear the lowest mask bit ...
-                if ((cur & 15u) == 0u) cur = 0u;  // ... and drop the entry once its mask is empty
+            if (__ballot(ent != 0u) == 0ull) break;
+            if (ent != 0u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(ent & 15u);
+                const uint32_t cand = 4u * (ent >> 4) + k;
+                ent &= ent - 1u;                  // clear the lowest mask bit ...
+                if ((ent & 15u) == 0u) ent = 0u;  // ... and drop the entry once its mask is empty
                 const float4 S = tab[cand];
                 const float ocx = o.x - S.x;
                 const float ocy = o.y - S.y;
@@ -599,13 +614,14 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __res
         // leaf steps run when every live lane is at a leaf, so both kinds of step run with many lanes.
         uint16_t* stack = waveCand + kWaveListBytes / 2 + lane;  // [slot][lane]
         const uint32_t topLevel = nLevels - 1u;
-        uint32_t sp = 0, nextTop = 0;
+        uint32_t sp = 0;
         for (;;) {
-            if (sp == 0 && nextTop < tot) {
-                const uint32_t t = overflow ? nextTop : (nextTop < c0 ? mine[nextTop] : mine[kMfmaSlots + (nextTop - c0)]);
-                ++nextTop;
-                stack[0] = (uint16_t)((topLevel << 13) | t);
-                sp = 1;
+            if (sp == 0) {
+                uint32_t t = 0;
+                if (next_candidate(cur, nxt, hOff, t)) {
+                    stack[0] = (uint16_t)((topLevel << 13) | t);
+                    sp = 1;
+                }
             }
             const bool has = sp > 0;
             if (__ballot(has) == 0ull) break;
@@ -924,7 +940,7 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
     const uint16_t* sgGlobal = p.sg_global;
     const uint32_t topLevel = p.n_levels - 1u;
     const uint32_t nTop = p.level_cnt[topLevel];
-    const uint32_t nTiles = (nTop + 31u) / 32u;
+    const uint32_t nTiles = mfma_tiles_for(nTop);  // even; nTop <= 128 => at most four
     if (kLds) {
         // LDS image (16-byte aligned pieces): scan | orig | materials (48 B = 3 float4) | radii | filter operands
         float4* ldsScan = tabBase;
