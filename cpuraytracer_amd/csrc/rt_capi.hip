@@ -73,7 +73,7 @@ struct rt_ctx {
     // scene
     bool hasScene = false;
     uint32_t n = 0;
-    DevBuf<float4> scan, tree;
+    DevBuf<float4> scan, tree, leaf;
     DevBuf<uint32_t> orig;
     DevBuf<uint16_t> sgCells, sgEntries, sgGlobal;
     bool useShadowGrid = true;  // RT_SHADOW_GRID=0 keeps every shadow ray on the scan
@@ -120,6 +120,7 @@ static uint32_t RowsetLocalRows(rt_rowset rs) {
 struct SceneLayout {
     std::vector<float4> scan;     // 4 * nGroups + 4 entries
     std::vector<uint32_t> orig;   // same length
+    std::vector<float4> leaf;     // same length: conservative bound of each single sphere (sphere-level filter)
     std::vector<float4> tree;     // bounds of every level, level 0 (the groups) first
     uint32_t levelOff[rtd::kMaxLevels] = {0}, levelCnt[rtd::kMaxLevels] = {0};
     uint32_t nLevels = 1;         // level nLevels-1 is the top level (<= topMax nodes), filtered on the matrix cores
@@ -128,9 +129,9 @@ struct SceneLayout {
 };
 
 // Conservative bounding sphere of a set of spheres, in the filter's (C, |C|^2 - Rf^2) form.
-static float4 BoundOf(const rt_sphere* sp, const std::vector<uint32_t>& ids, float* normOut) {
+static float4 BoundOf(const rt_sphere* sp, const std::vector<uint32_t>& ids, float* normOut, float marginK) {
     if (ids.empty()) return make_float4(0.f, 0.f, 0.f, 1e30f);  // never a candidate
-    const double kEps = (double)rtd::kMarginK * 5.9604644775390625e-08;  // K * eps (rt_kernels.h kMarginRel)
+    const double kEps = (double)marginK * 5.9604644775390625e-08;  // K * eps: K is that of the unit testing this bound (rt_kernels.h)
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (uint32_t k : ids) {
         const double c[3] = {sp[k].cx, sp[k].cy, sp[k].cz};
@@ -217,25 +218,28 @@ static void BuildLayout(const rt_sphere* sp, uint32_t n, uint32_t topMax, SceneL
             L.orig[(size_t)gi * 4 + m] = k;
         }
     }
-    // levels: level 0 = the groups; level k+1 node j = level-k nodes 4j .. 4j+3; stop at <= topMax nodes
-    std::vector<std::vector<uint32_t>> members = groups;
-    L.tree.clear();
-    L.nLevels = 0;
-    for (;;) {
-        const uint32_t lvl = L.nLevels++;
-        L.levelOff[lvl] = (uint32_t)L.tree.size();
-        L.levelCnt[lvl] = (uint32_t)members.size();
-        for (const auto& ids : members) L.tree.push_back(BoundOf(sp, ids, &L.boundNorm));
-        if (members.size() <= topMax || L.nLevels == rtd::kMaxLevels) break;
-        while (members.size() & 3u) {  // pad this level to whole parents
-            members.push_back({});
-            L.tree.push_back(BoundOf(sp, {}, nullptr));
-            L.levelCnt[lvl] += 1;
-        }
-        std::vector<std::vector<uint32_t>> up(members.size() / 4);
+    L.leaf.assign(L.scan.size(), BoundOf(sp, {}, nullptr, rtd::kMarginKLeaf));  // padding entries are never candidates
+    for (size_t e = 0; e < L.orig.size(); ++e)
+        if (L.orig[e] != 0xffffffffu) L.leaf[e] = BoundOf(sp, {L.orig[e]}, nullptr, rtd::kMarginKLeaf);
+    // levels: level 0 = the groups; level k+1 node j = level-k nodes 4j .. 4j+3; stop at <= topMax nodes.  The top
+    // level is tested by the matrix-core filter (margin K = kMarginK), the levels below it on the VALU (kMarginKValu).
+    std::vector<std::vector<std::vector<uint32_t>>> levels;
+    levels.push_back(groups);
+    while (levels.back().size() > topMax && levels.size() < rtd::kMaxLevels) {
+        std::vector<std::vector<uint32_t>>& cur = levels.back();
+        while (cur.size() & 3u) cur.push_back({});  // pad this level to whole parents
+        std::vector<std::vector<uint32_t>> up(cur.size() / 4);
         for (size_t j = 0; j < up.size(); ++j)
-            for (int q = 0; q < 4; ++q) up[j].insert(up[j].end(), members[4 * j + q].begin(), members[4 * j + q].end());
-        members.swap(up);
+            for (int q = 0; q < 4; ++q) up[j].insert(up[j].end(), cur[4 * j + q].begin(), cur[4 * j + q].end());
+        levels.push_back(std::move(up));
+    }
+    L.tree.clear();
+    L.nLevels = (uint32_t)levels.size();
+    for (uint32_t lvl = 0; lvl < L.nLevels; ++lvl) {
+        L.levelOff[lvl] = (uint32_t)L.tree.size();
+        L.levelCnt[lvl] = (uint32_t)levels[lvl].size();
+        const float K = lvl + 1 == L.nLevels ? rtd::kMarginK : rtd::kMarginKValu;
+        for (const auto& ids : levels[lvl]) L.tree.push_back(BoundOf(sp, ids, &L.boundNorm, K));
     }
 }
 // ---------------------------------------------------------------------------------- shadow index
@@ -377,15 +381,16 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     const bool tree = ctx->useMfma && tp.n_levels > 1;  // deeper hierarchy: tables stay in global memory (L2)
     const uint32_t topCnt = tp.level_cnt[tp.n_levels - 1];
     const size_t candBytes = (size_t)wavesPerBlock * (tree ? rtd::kWaveCandBytes : rtd::kWaveListBytes);
-    const bool flat = !tree && useLds && ctx->useMfma && (candBytes + lds + MfmaOpsBytesFor(topCnt)) <= 160 * 1024;
+    const size_t leafBytes = (size_t)tp.n_padded * 16;  // one-sphere bounds, staged next to the scan table by the flat scan
+    const bool flat = !tree && useLds && ctx->useMfma && (candBytes + lds + leafBytes + MfmaOpsBytesFor(topCnt)) <= 160 * 1024;
     const bool ldsTables = useLds && !tree;
     size_t sgBytes = (flat && tp.sg_enabled) ? (((size_t)tp.sg_nx * tp.sg_ny + 1 + tp.sg_nentries + tp.sg_nglobal) * 2 + 15) / 16 * 16 : 0;
-    if (candBytes + lds + MfmaOpsBytesFor(topCnt) + sgBytes > 160 * 1024) sgBytes = 0;  // index stays in global memory (L2)
+    if (candBytes + lds + leafBytes + MfmaOpsBytesFor(topCnt) + sgBytes > 160 * 1024) sgBytes = 0;  // index stays in global memory (L2)
     tp.sg_in_lds = sgBytes ? 1u : 0u;
     size_t treeBytes = tree ? (size_t)(tp.level_off[tp.n_levels - 1] + topCnt) * 16 : 0;
     if (candBytes + MfmaOpsBytesFor(topCnt) + treeBytes > 160 * 1024) treeBytes = 0;
     tp.tree_in_lds = treeBytes ? 1u : 0u;
-    const size_t ldsBytes = candBytes + (ldsTables ? lds : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0) + sgBytes + treeBytes;
+    const size_t ldsBytes = candBytes + (ldsTables ? lds : 0) + (flat ? leafBytes : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0) + sgBytes + treeBytes;
 #define RT_LAUNCH(LDS, T, M)                                                                                                   \
     do {                                                                                                                      \
         if (ldsBytes > 48 * 1024)                                                                                             \
@@ -525,6 +530,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     if ((rc = ctx->scan.Reserve(nPad)) != RT_OK) return rc;
     if ((rc = ctx->orig.Reserve(nPad)) != RT_OK) return rc;
     if ((rc = ctx->tree.Reserve(L.tree.size())) != RT_OK) return rc;
+    if ((rc = ctx->leaf.Reserve(nPad)) != RT_OK) return rc;
     if ((rc = ctx->radius.Reserve(n)) != RT_OK) return rc;
     if ((rc = ctx->mats.Reserve(n)) != RT_OK) return rc;
     std::vector<float> rad(n);
@@ -533,6 +539,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     RT_HIP(hipMemcpy(ctx->scan.ptr, L.scan.data(), nPad * sizeof(float4), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->orig.ptr, L.orig.data(), nPad * sizeof(uint32_t), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->tree.ptr, L.tree.data(), L.tree.size() * sizeof(float4), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->leaf.ptr, L.leaf.data(), nPad * sizeof(float4), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->radius.ptr, rad.data(), n * sizeof(float), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->mats.ptr, materials, n * sizeof(rt_material), hipMemcpyHostToDevice));
 
@@ -569,6 +576,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     }
     b.scan = ctx->scan.ptr;
     b.orig = ctx->orig.ptr;
+    b.leaf = ctx->leaf.ptr;
     b.tree = ctx->tree.ptr;
     b.n_groups = L.nGroups;
     b.n_levels = L.nLevels;

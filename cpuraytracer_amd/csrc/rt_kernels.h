@@ -68,6 +68,7 @@ struct TraceParams {
     // update breaks ties by the ORIGINAL list index (orig[]).
     const float4* scan;        // [n_padded] cx, cy, cz, r*r in clustered order (padding: never-hit entries, r*r = -1e30)
     const uint32_t* orig;      // [n_padded] original list index of each entry (0xffffffff for padding)
+    const float4* leaf;        // [n_padded] conservative one-sphere bounds (cx, cy, cz, |c|^2 - rf^2) for the sphere-level filter
     // Bounds hierarchy (4-ary): level 0 = the groups, level k+1 node j = level-k nodes 4j..4j+3; the top level
     // (<= 128 nodes) is filtered on the matrix cores, lower levels are descended per lane.
     const float4* tree;        // all levels, level 0 first: Cx, Cy, Cz, |C|^2 - Rf^2
@@ -371,7 +372,10 @@ constexpr uint32_t kMfmaSlots = 20;                                    // phase-
 constexpr uint32_t kStackSlots = 24;                                    // per-lane descent stack (tree scan): 3 * levels + 1 needed
 constexpr uint32_t kWaveListBytes = 64 * kMfmaSlots * 2;                // phase-A lists = 2560 B per wave
 constexpr uint32_t kWaveCandBytes = kWaveListBytes + 64 * kStackSlots * 2;  // + stack = 5632 B per wave
-constexpr float kMarginK = 4096.f;                                      // K of the filter margin (host uses the same K)
+// K of the filter margins (units of eps * a * G; the host folds the same K into each bound): the matrix-core level needs
+// 101*16 (exact-path rounding, amplified by the member offsets) + ~600 (split-bf16 operands); levels tested on the VALU
+// in f32 need 101*16 + 30; a one-sphere bound (offset 0) needs 16 + 30.
+constexpr float kMarginK = 4096.f, kMarginKValu = 2048.f, kMarginKLeaf = 64.f;
 constexpr float kMarginRel = kMarginK * 5.9604645e-8f;                 // K * eps
 constexpr uint32_t kOpsPerTile = 8 * 64;                                // dwords of the group operand image per 32-group tile
 
@@ -442,6 +446,18 @@ RT_DEV void mfma_post(const f32x16& Tb, const f32x16& Tg, float cray, float bthr
     }
 }
 
+// The filter formula on the VALU (any rounding; the bounds' margins cover it): sign bit set = the bound (C, W) cannot
+// contain an acceptable root of the ray.  dO = d.o, m2a = -2a, cr = a|o|^2 (1 - 2 K eps), bt = the "behind" threshold.
+RT_DEV int bound_rejected(const float4 B, V3 o, V3 d, float a, float dO, float m2a, float cr, float bt) {
+    const float dC = __builtin_fmaf(d.z, B.z, __builtin_fmaf(d.y, B.y, d.x * B.x));
+    const float oC = __builtin_fmaf(o.z, B.z, __builtin_fmaf(o.y, B.y, o.x * B.x));
+    const float b = dO - dC;
+    const float t = cr + __builtin_fmaf(m2a, oC, a * B.w);
+    const float f = __builtin_fmaf(b, b, -t);
+    const float u = bt - b;
+    return __float_as_int(f) | (__float_as_int(u) & ~__float_as_int(t));
+}
+
 // One candidate of a ray's 128-bit bitmap (two 64-bit halves: the rows filtered by lanes l&31 and (l&31)+32).  Returns
 // false when none is left.  Leading-zero order; bit N (from the top) of half h is group 16 h + N + (N & 48).
 RT_DEV bool next_candidate(unsigned long long& cur, unsigned long long& nxt, uint32_t& hOff, uint32_t& gid) {
@@ -458,7 +474,8 @@ RT_DEV bool next_candidate(unsigned long long& cur, unsigned long long& nxt, uin
 }
 
 template <bool kTree>
-RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __restrict__ orig, const float* __restrict__ ops, uint32_t nTiles,
+RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restrict__ leaf, const uint32_t* __restrict__ orig,
+                           const float* __restrict__ ops, uint32_t nTiles,
                            uint32_t nTop, const float4* __restrict__ tree, const uint32_t* levelOff, uint32_t nLevels, float boundNorm, V3 o,
                            V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand, uint32_t lane, unsigned long long* dbg) {
     const float a = dot3(d, d);
@@ -471,6 +488,8 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __res
     // a dead ray's a*cc~ is made huge so that nothing is ever recorded for it
     const float oo = dot3(o, o);
     const float cr = live ? (a * oo) * (1.f - 2.f * kMarginRel) : 1e30f;
+    const float crValu = (a * oo) * (1.f - 2.f * kMarginKValu * 5.9604645e-8f);  // per-ray margin of the VALU-tested levels
+    const float crLeaf = (a * oo) * (1.f - 2.f * kMarginKLeaf * 5.9604645e-8f);  // ... and of the one-sphere bounds
     const float bt = 1e-4f * __builtin_sqrtf(a) * (__builtin_sqrtf(oo) + boundNorm);
     // ray-side operands: values (k = 0,1 | 2,3) of the b chain [dx, dy | dz, d.o] and of the a*cc chain [gx, gy | gz, a].
     // Tile 0 (rays of lanes 0-31) takes k = 0,1 from the owner and k = 2,3 from lane+32; tile 1 the other way round:
@@ -562,7 +581,14 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __res
             dbg[6] += 1;
 #endif
             if (has) {
-                const uint32_t m = group_root_mask(tab, 4u * gid, o, d, a);
+                // sphere-level filter: the same conservative formula on each member's own bound (13 operations instead
+                // of the 23 of the exact discriminant + root test; phase B decides exactly).  Bit 3-k = sphere k.
+                const float4* lb = leaf + 4u * gid;
+                uint32_t rb = 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k)
+                    rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(lb[k], o, d, a, dO, m2a, crLeaf, bt), 31);
+                const uint32_t m = ~rb & 15u;
                 if (m != 0u) {
                     if (__builtin_expect(nq < kMfmaSlots, 1)) {
                         own[nq] = (uint16_t)(gid << 4 | m);
@@ -586,7 +612,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __res
             }
             if (__ballot(ent != 0u) == 0ull) break;
             if (ent != 0u) {
-                const uint32_t k = (uint32_t)__builtin_ctz(ent & 15u);
+                const uint32_t k = 3u - (uint32_t)__builtin_ctz(ent & 15u);
                 const uint32_t cand = 4u * (ent >> 4) + k;
                 ent &= ent - 1u;                  // clear the lowest mask bit ...
                 if ((ent & 15u) == 0u) ent = 0u;  // ... and drop the entry once its mask is empty
@@ -600,7 +626,8 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __res
                 const float sq = __builtin_sqrtf(e);
                 float t = (-b - sq) / a;               // ray-tracing.cpp:56
                 if (!(t > 0.001f)) t = (-b + sq) / a;  // :69
-                if (t > 0.001f && (t < tmin || (t == tmin && idx >= 0 && orig[cand] < orig[idx]))) {
+                // `e > 0` is the reference's own test (ray-tracing.cpp:54); phase A only promised "possible"
+                if (e > 0.f && t > 0.001f && (t < tmin || (t == tmin && idx >= 0 && orig[cand] < orig[idx]))) {
                     tmin = t;
                     idx = (int)cand;
                 }
@@ -638,14 +665,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const uint32_t* __res
                     const float4* ch = tree + off + 4u * j;
 #pragma unroll
                     for (uint32_t q = 0; q < 4; ++q) {
-                        const float4 B = ch[q];
-                        const float dC = __builtin_fmaf(d.z, B.z, __builtin_fmaf(d.y, B.y, d.x * B.x));
-                        const float oC = __builtin_fmaf(o.z, B.z, __builtin_fmaf(o.y, B.y, o.x * B.x));
-                        const float b = dO - dC;
-                        const float t = cr + __builtin_fmaf(m2a, oC, a * B.w);
-                        const float f = __builtin_fmaf(b, b, -t);
-                        const float u = bt - b;
-                        const int rej = __float_as_int(f) | (__float_as_int(u) & ~__float_as_int(t));
+                        const int rej = bound_rejected(ch[q], o, d, a, dO, m2a, crValu, bt);
                         if (rej >= 0) {
                             stack[sp * kWaveSize] = (uint16_t)((cl << 13) | (4u * j + q));
                             ++sp;
@@ -927,6 +947,7 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
     extern __shared__ float4 smem[];
     const float4* scanTab = p.scan;
     const uint32_t* origTab = p.orig;
+    const float4* leafTab = p.leaf;
     const float* radTab = p.radius;
     const rt_material* matTab = p.mats;
     // per-wave candidate regions first (kWaveCandBytes each; the VALU scan uses the first 2 KiB of its region)
@@ -942,9 +963,11 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
     const uint32_t nTop = p.level_cnt[topLevel];
     const uint32_t nTiles = mfma_tiles_for(nTop);  // even; nTop <= 128 => at most four
     if (kLds) {
-        // LDS image (16-byte aligned pieces): scan | orig | materials (48 B = 3 float4) | radii | filter operands
+        // LDS image (16-byte aligned pieces): scan | one-sphere bounds (matrix-core scan only) | orig | materials (48 B =
+        // 3 float4) | radii | filter operands | shadow index
         float4* ldsScan = tabBase;
-        uint32_t* ldsOrig = reinterpret_cast<uint32_t*>(ldsScan + p.n_padded);
+        float4* ldsLeaf = ldsScan + p.n_padded;
+        uint32_t* ldsOrig = reinterpret_cast<uint32_t*>(ldsLeaf + (kScan == 1 ? p.n_padded : 0u));
         float4* ldsMat = reinterpret_cast<float4*>(ldsOrig + p.n_padded);  // n_padded is a multiple of 4
         const uint32_t nMatLds = p.mats_in_lds ? p.n : 0u;
         float* ldsRad = reinterpret_cast<float*>(ldsMat + (size_t)nMatLds * 3);
@@ -952,6 +975,7 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
         for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) {
             ldsScan[k] = p.scan[k];
             ldsOrig[k] = p.orig[k];
+            if (kScan == 1) ldsLeaf[k] = p.leaf[k];
         }
         for (uint32_t k = threadIdx.x; k < nMatLds * 3; k += blockDim.x) ldsMat[k] = gMat[k];
         for (uint32_t k = threadIdx.x; k < p.n; k += blockDim.x) ldsRad[k] = p.radius[k];
@@ -973,6 +997,7 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
         __syncthreads();
         scanTab = ldsScan;
         origTab = ldsOrig;
+        if (kScan == 1) leafTab = ldsLeaf;
         radTab = ldsRad;
         if (p.mats_in_lds) matTab = reinterpret_cast<const rt_material*>(ldsMat);
     } else if (kMfma) {
@@ -1066,7 +1091,7 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
         if (kMfma) {
             // every lane takes part: lane l also supplies operands for, and filters half the spheres of,
             // the ray owned by lane l^32, whether or not its own ray is live
-            scan_list_mfma<kScan == 2>(scanTab, origTab, mfmaOps, nTiles, nTop, treeTab, p.level_off, p.n_levels, p.bound_norm, ro, rd,
+            scan_list_mfma<kScan == 2>(scanTab, leafTab, origTab, mfmaOps, nTiles, nTop, treeTab, p.level_off, p.n_levels, p.bound_norm, ro, rd,
                                        state != kIdle, tmin, idx, waveCand, lane, dbgScan);
         } else if (state != kIdle) {
             scan_list_deferred(scanTab, origTab, p.n_padded, ro, rd, tmin, idx, cand);
