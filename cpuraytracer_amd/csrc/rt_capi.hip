@@ -98,6 +98,7 @@ struct rt_ctx {
     uint32_t blockThreads = 256;
     bool useMfma = true;  // matrix-core pre-filter for the list scan (RT_SCAN=valu disables)
     bool matsInLds = true;   // RT_MATS_LDS=0 leaves the material table in global memory (frees 48 B/sphere of LDS)
+    bool useRayCache = true;
     uint32_t treeTop = 128;  // largest top level the matrix-core filter takes (4 tiles of 32); RT_TREE_TOP overrides
     bool forceGlobal = false;
 };
@@ -390,21 +391,30 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     size_t treeBytes = tree ? (size_t)(tp.level_off[tp.n_levels - 1] + topCnt) * 16 : 0;
     if (candBytes + MfmaOpsBytesFor(topCnt) + treeBytes > 160 * 1024) treeBytes = 0;
     tp.tree_in_lds = treeBytes ? 1u : 0u;
-    const size_t ldsBytes = candBytes + (ldsTables ? lds : 0) + (flat ? leafBytes : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0) + sgBytes + treeBytes;
-#define RT_LAUNCH(LDS, T, M)                                                                                                   \
+    size_t ldsBytes = candBytes + (ldsTables ? lds : 0) + (flat ? leafBytes : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0) + sgBytes + treeBytes;
+    // per-wave caches of prepared paths go last, when there is room left (RT_RAY_CACHE=0 disables them)
+    ldsBytes = (ldsBytes + 15) / 16 * 16;
+    tp.ray_cache_off16 = 0;
+    if (ctx->useRayCache && ldsBytes + (size_t)wavesPerBlock * rtd::kRayCacheBytes <= 160 * 1024 / ctx->blocksPerCu) {
+        tp.ray_cache_off16 = (uint32_t)(ldsBytes / 16);
+        ldsBytes += (size_t)wavesPerBlock * rtd::kRayCacheBytes;
+    }
+#define RT_LAUNCH_C(LDS, T, M, C)                                                                                                  \
     do {                                                                                                                      \
         if (ldsBytes > 48 * 1024)                                                                                             \
-            RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rtd::rt_trace_kernel<LDS, T, M>),                        \
+            RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rtd::rt_trace_kernel<LDS, T, M, C>),                     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));                           \
-        hipLaunchKernelGGL((rtd::rt_trace_kernel<LDS, T, M>), dim3(blocks), dim3(T), ldsBytes, ctx->stream, tp);              \
+        hipLaunchKernelGGL((rtd::rt_trace_kernel<LDS, T, M, C>), dim3(blocks), dim3(T), ldsBytes, ctx->stream, tp);           \
+    } while (0)
+#define RT_LAUNCH(LDS, T, M)                        \
+    do {                                            \
+        if (tp.ray_cache_off16) RT_LAUNCH_C(LDS, T, M, true); \
+        else RT_LAUNCH_C(LDS, T, M, false);         \
     } while (0)
 #define RT_LAUNCH_T(LDS, M)                                            \
     do {                                                               \
         if (ctx->blockThreads == 1024) RT_LAUNCH(LDS, 1024, M);        \
-        else if (ctx->blockThreads == 768) RT_LAUNCH(LDS, 768, M);     \
-        else if (ctx->blockThreads == 640) RT_LAUNCH(LDS, 640, M);     \
         else if (ctx->blockThreads == 512) RT_LAUNCH(LDS, 512, M);     \
-        else if (ctx->blockThreads == 384) RT_LAUNCH(LDS, 384, M);     \
         else RT_LAUNCH(LDS, 256, M);                                   \
     } while (0)
     if (tree) RT_LAUNCH_T(false, 2);
@@ -413,6 +423,7 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     else RT_LAUNCH_T(false, 0);
 #undef RT_LAUNCH_T
 #undef RT_LAUNCH
+#undef RT_LAUNCH_C
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
@@ -457,6 +468,7 @@ int rt_create(int device_ordinal, rt_ctx** out) {
         ctx->useMfma = !(scan && std::strcmp(scan, "valu") == 0);
         ctx->matsInLds = EnvU32("RT_MATS_LDS", 1) != 0;
         ctx->useShadowGrid = EnvU32("RT_SHADOW_GRID", 1) != 0;
+        ctx->useRayCache = EnvU32("RT_RAY_CACHE", 1) != 0;
         ctx->treeTop = EnvU32("RT_TREE_TOP", 128);
         if (ctx->treeTop < 4 || ctx->treeTop > 128) ctx->treeTop = 128;
     }
@@ -466,10 +478,7 @@ int rt_create(int device_ordinal, rt_ctx** out) {
     if (ctx->blocksPerCu == 0) ctx->blocksPerCu = 1;
     ctx->forceGlobal = EnvU32("RT_FORCE_GLOBAL_TABLES", 0) != 0;
     ctx->blockThreads = EnvU32("RT_BLOCK_THREADS", ctx->useMfma ? 1024 : 256);
-    if (ctx->blockThreads != 256 && ctx->blockThreads != 384 && ctx->blockThreads != 512 && ctx->blockThreads != 640 &&
-        ctx->blockThreads != 768 &&
-        ctx->blockThreads != 1024)
-        ctx->blockThreads = 256;
+    if (ctx->blockThreads != 256 && ctx->blockThreads != 512 && ctx->blockThreads != 1024) ctx->blockThreads = 256;
     int rc = ctx->queue.Reserve(1);
     if (rc == RT_OK) rc = ctx->counters.Reserve(2);
     if (rc != RT_OK) {

@@ -108,6 +108,7 @@ struct TraceParams {
     uint32_t lens_k0;
     float* samples;             // [total_paths][3] radiance * exposure
     uint32_t* trav_out;         // optional per-path traversal counts
+    uint32_t ray_cache_off16;  // float4 offset of the per-wave prepared-path caches in dynamic LDS, 0 = no cache
     uint32_t* queue_head;       // global work counter, zeroed before launch
     unsigned long long* counters;  // [0] traversals, [1] segments
 };
@@ -377,6 +378,7 @@ constexpr uint32_t kWaveCandBytes = kWaveListBytes + 64 * kStackSlots * 2;  // +
 // in f32 need 101*16 + 30; a one-sphere bound (offset 0) needs 16 + 30.
 constexpr float kMarginK = 4096.f, kMarginKValu = 2048.f, kMarginKLeaf = 64.f;
 constexpr float kMarginRel = kMarginK * 5.9604645e-8f;                 // K * eps
+constexpr uint32_t kRayCacheBytes = 64 * 48;                            // per-wave cache of prepared paths
 constexpr uint32_t kOpsPerTile = 8 * 64;                                // dwords of the group operand image per 32-group tile
 
 // Split-bf16 operands.  An f32 value v is carried as h + l with h = bf16(v) and l = bf16(v - h) (both round to
@@ -931,6 +933,22 @@ RT_DEV uint32_t prefix_count(uint64_t mask) {
 
 enum : uint32_t { kIdle = 0u, kNeedClosest = 1u, kNeedShadow = 2u };
 
+// Work-item index -> (column i, global row j, sample s): the explicit path list of the unit tests, or pixel-major
+// order [local pixel][sample of the pass] over the rows of this shard.
+RT_DEV void path_coordinates(const TraceParams& p, uint32_t q, uint32_t& i, uint32_t& j, uint32_t& s) {
+    if (p.path_list) {
+        i = p.path_list[3 * q];
+        j = p.path_list[3 * q + 1];
+        s = p.path_list[3 * q + 2];
+    } else {
+        const uint32_t pl = q / p.spp_pass;
+        s = p.s0 + (q - pl * p.spp_pass);
+        const uint32_t lr = pl / p.W;
+        i = pl - lr * p.W;
+        j = rowset_global_row(p.rs, lr);
+    }
+}
+
 
 
 // ============================================================================ megakernel
@@ -941,8 +959,8 @@ enum : uint32_t { kIdle = 0u, kNeedClosest = 1u, kNeedShadow = 2u };
 // max_depth+1 segments have finished.
 // kScan: 0 = VALU sign filter per group (any scene size), 1 = matrix-core filter over the groups (tables in LDS),
 // 2 = matrix-core filter over the top level of the bounds hierarchy + per-lane descent (tables through L2).
-template <bool kLds, int kThreads, int kScan>
-__global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_kernel(const TraceParams p) {
+template <bool kLds, int kThreads, int kScan, bool kCache>
+__global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams p) {
     constexpr bool kMfma = kScan != 0;
     extern __shared__ float4 smem[];
     const float4* scanTab = p.scan;
@@ -1029,9 +1047,10 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
     bool contAfterShadow = false, pathScattered = false;
     uint32_t nTrav = 0, nSeg = 0;
 
-    // wave-uniform queue window
-    uint32_t blkNext = 0, blkEnd = 0;
+    // wave-uniform queue window and prepared-path cache (48-byte slots: origin, direction, stream state, path index)
+    uint32_t blkNext = 0, blkEnd = 0, cachePos = 0, cacheCnt = 0;
     bool queueEmpty = false;
+    float4* rayCache = kCache ? smem + p.ray_cache_off16 + (threadIdx.x / kWaveSize) * (kRayCacheBytes / 16) : nullptr;
 
     unsigned long long dbgScan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)dbgScan;
@@ -1041,46 +1060,94 @@ __global__ void __launch_bounds__(kThreads, (kThreads == 640 ? 5 : 1)) rt_trace_
     for (;;) {
         RT_STAMP(ts0);
         // ------------------------------------------------ refill idle lanes (ballot + prefix)
+        // New paths come from a per-wave cache of 64 prepared paths in LDS: when it runs empty ALL 64 lanes generate
+        // the next 64 paths of the wave's queue block at once (index arithmetic, stream seeding, Camera::GetRay with
+        // its two normalisations: ~350 instructions at full lane utilisation instead of once per handful of idle
+        // lanes), and an idle lane just pops a 48-byte slot.  In-flight paths are untouched: the generation only uses
+        // temporaries.  Without room for the cache in LDS (kCache == false) idle lanes generate their own path.
         uint64_t idleMask = __ballot(state == kIdle);
-        while (idleMask != 0ull && !queueEmpty) {
-            if (blkNext == blkEnd) {
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(p.queue_head, kQueueBlock);
-                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                blkNext = b < p.total_paths ? b : p.total_paths;
-                blkEnd = (b + kQueueBlock) < p.total_paths ? (b + kQueueBlock) : p.total_paths;
-                if (b >= p.total_paths) {
-                    queueEmpty = true;
-                    break;
+        if (kCache) {
+            while (idleMask != 0ull) {
+                if (cachePos == cacheCnt) {
+                    if (queueEmpty) break;
+                    if (blkNext == blkEnd) {
+                        uint32_t b = 0;
+                        if (lane == 0) b = atomicAdd(p.queue_head, kQueueBlock);
+                        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                        blkNext = b < p.total_paths ? b : p.total_paths;
+                        blkEnd = (b + kQueueBlock) < p.total_paths ? (b + kQueueBlock) : p.total_paths;
+                        if (b >= p.total_paths) {
+                            queueEmpty = true;
+                            break;
+                        }
+                    }
+                    const uint32_t nGen = (blkEnd - blkNext) < (uint32_t)kWaveSize ? (blkEnd - blkNext) : (uint32_t)kWaveSize;
+                    if (lane < nGen) {
+                        const uint32_t qn = blkNext + lane;
+                        uint32_t i, j, s;
+                        path_coordinates(p, qn, i, j, s);
+                        const Rng g = rng_seed(p.seed, j * p.W + i, s);
+                        V3 go, gd;
+                        gen_primary_ray(p, i, j, s, go, gd);
+                        float4* slot = rayCache + 3u * lane;
+                        slot[0] = make_float4(go.x, go.y, go.z, gd.x);
+                        slot[1] = make_float4(gd.y, gd.z, __uint_as_float(g.s0), __uint_as_float(g.s1));
+                        slot[2] = make_float4(__uint_as_float(g.s2), __uint_as_float(g.s3), __uint_as_float(qn), 0.f);
+                    }
+                    blkNext += nGen;
+                    cacheCnt = nGen;
+                    cachePos = 0;
                 }
-            }
-            const uint32_t avail = blkEnd - blkNext;
-            const uint32_t want = (uint32_t)__popcll(idleMask);
-            const uint32_t rank = prefix_count(idleMask);
-            if (state == kIdle && rank < avail) {
-                q = blkNext + rank;
-                uint32_t i, j, s;
-                if (p.path_list) {
-                    i = p.path_list[3 * q];
-                    j = p.path_list[3 * q + 1];
-                    s = p.path_list[3 * q + 2];
-                } else {
-                    const uint32_t pl = q / p.spp_pass;
-                    s = p.s0 + (q - pl * p.spp_pass);
-                    const uint32_t lr = pl / p.W;
-                    i = pl - lr * p.W;
-                    j = rowset_global_row(p.rs, lr);
+                const uint32_t avail = cacheCnt - cachePos;
+                const uint32_t want = (uint32_t)__popcll(idleMask);
+                const uint32_t rank = prefix_count(idleMask);
+                if (state == kIdle && rank < avail) {
+                    const float4* slot = rayCache + 3u * (cachePos + rank);
+                    const float4 A = slot[0], B = slot[1], C = slot[2];
+                    ro = v3(A.x, A.y, A.z);
+                    rd = v3(A.w, B.x, B.y);
+                    draws.rng = Rng{__float_as_uint(B.z), __float_as_uint(B.w), __float_as_uint(C.x), __float_as_uint(C.y)};
+                    q = __float_as_uint(C.z);
+                    thr = v3(1.f, 1.f, 1.f);
+                    rad = v3(0.f, 0.f, 0.f);
+                    depth = 0;
+                    pathTrav = 0;
+                    state = kNeedClosest;
                 }
-                draws.rng = rng_seed(p.seed, j * p.W + i, s);
-                gen_primary_ray(p, i, j, s, ro, rd);
-                thr = v3(1.f, 1.f, 1.f);
-                rad = v3(0.f, 0.f, 0.f);
-                depth = 0;
-                pathTrav = 0;
-                state = kNeedClosest;
+                cachePos += want < avail ? want : avail;
+                idleMask = __ballot(state == kIdle);
             }
-            blkNext += want < avail ? want : avail;
-            idleMask = __ballot(state == kIdle);
+        } else {
+            while (idleMask != 0ull && !queueEmpty) {
+                if (blkNext == blkEnd) {
+                    uint32_t b = 0;
+                    if (lane == 0) b = atomicAdd(p.queue_head, kQueueBlock);
+                    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                    blkNext = b < p.total_paths ? b : p.total_paths;
+                    blkEnd = (b + kQueueBlock) < p.total_paths ? (b + kQueueBlock) : p.total_paths;
+                    if (b >= p.total_paths) {
+                        queueEmpty = true;
+                        break;
+                    }
+                }
+                const uint32_t avail = blkEnd - blkNext;
+                const uint32_t want = (uint32_t)__popcll(idleMask);
+                const uint32_t rank = prefix_count(idleMask);
+                if (state == kIdle && rank < avail) {
+                    q = blkNext + rank;
+                    uint32_t i, j, s;
+                    path_coordinates(p, q, i, j, s);
+                    draws.rng = rng_seed(p.seed, j * p.W + i, s);
+                    gen_primary_ray(p, i, j, s, ro, rd);
+                    thr = v3(1.f, 1.f, 1.f);
+                    rad = v3(0.f, 0.f, 0.f);
+                    depth = 0;
+                    pathTrav = 0;
+                    state = kNeedClosest;
+                }
+                blkNext += want < avail ? want : avail;
+                idleMask = __ballot(state == kIdle);
+            }
         }
         if (__ballot(state != kIdle) == 0ull) break;  // queue empty and every lane drained
 
