@@ -330,8 +330,10 @@ static void BuildShadowGrid(const rt_sphere* sp, const SceneLayout& L, const flo
     std::vector<std::vector<uint16_t>> cells((size_t)G.nx * G.ny);
     const size_t ncell = cells.size();
     for (const Foot& f : feet) {
-        long x0 = cellOf(f.u - f.rho, G.u0, G.nx) - 1, x1 = cellOf(f.u + f.rho, G.u0, G.nx) + 1;  // +-1 cell: float cell arithmetic slack
-        long y0 = cellOf(f.v - f.rho, G.v0, G.ny) - 1, y1 = cellOf(f.v + f.rho, G.v0, G.ny) + 1;
+        // no extra cell of slack: rho already carries 1e-5 (P0 + |c| + 1), at least 20x the error of the device's float
+        // projection and cell arithmetic (<= ~5e-7 P0 for |p| <= P0), and floor() is monotone
+        long x0 = cellOf(f.u - f.rho, G.u0, G.nx), x1 = cellOf(f.u + f.rho, G.u0, G.nx);
+        long y0 = cellOf(f.v - f.rho, G.v0, G.ny), y1 = cellOf(f.v + f.rho, G.v0, G.ny);
         const bool outside = x1 < 0 || y1 < 0 || x0 >= (long)G.nx || y0 >= (long)G.ny;
         x0 = std::max(0L, x0); y0 = std::max(0L, y0);
         x1 = std::min((long)G.nx - 1, x1); y1 = std::min((long)G.ny - 1, y1);

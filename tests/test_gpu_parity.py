@@ -265,6 +265,24 @@ def test_forced_global_tables_equal_lds_tables(hip, scenes_mod, monkeypatch):
     assert_same(a, b, "LDS-staged vs global-memory tables")
 
 
+def test_prepared_path_cache_equals_per_lane_generation(hip, scenes_mod, monkeypatch):
+    """RT_RAY_CACHE=0 makes idle lanes generate their own path instead of popping the wave's LDS cache of 64
+    prepared paths: same image, same traversal counters (tail blocks shorter than 64 paths included: 97x61 pixels)."""
+    from cpuraytracer_amd import HipRenderer
+    sc = scenes_mod.build_scene("cover", 1, 97, 61)
+    hip.upload(sc)
+    sa = hip.render(97, 61, 1, 4, 50, 1)
+    a, _ = hip.download(ldr=False)
+    monkeypatch.setenv("RT_RAY_CACHE", "0")
+    r2 = HipRenderer(0)
+    r2.upload(sc)
+    sb = r2.render(97, 61, 1, 4, 50, 1)
+    b, _ = r2.download(ldr=False)
+    r2.close()
+    assert_same(a, b, "cached vs per-lane path generation")
+    assert (sa.traversals, sa.segments) == (sb.traversals, sb.segments)
+
+
 # ----------------------------------------------- the scan's filter machinery (DESIGN.md §5.1)
 def _custom_scene(oracle, centers, radii, types, cam_origin, cam_look, vfov, aspect, aperture=0.0):
     """Flat scene from arrays (tests only): colours/smoothness fixed, camera via the oracle's Camera."""
@@ -335,8 +353,8 @@ def test_bounds_hierarchy_descent_equals_flat_filter(hip, scenes_mod, monkeypatc
 
 
 def test_candidate_list_overflow_falls_back_exactly(hip, oracle):
-    """A ray skimming a long row of spheres passes the filter for far more groups than a candidate sub-list holds
-    (14): the owner lane must then resolve every group, and the image must still equal the oracle's."""
+    """A ray skimming a long row of 240 spheres has possible roots in up to 60 groups, more than the 20 entries the
+    lane's phase-A list holds: the surplus groups are resolved on the spot, and the image must still equal the oracle's."""
     n = 240
     centers = np.stack([np.arange(n) * 0.5 - 30.0, np.zeros(n), np.full(n, 5.0)], 1).astype(np.float32)
     centers = np.concatenate([centers, [[0.0, -1000.2, 5.0]]]).astype(np.float32)
