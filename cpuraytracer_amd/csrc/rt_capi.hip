@@ -141,8 +141,39 @@ static float4 BoundOf(const rt_sphere* sp, const std::vector<uint32_t>& ids, flo
             hi[a] = std::max(hi[a], c[a] + (double)sp[k].r);
         }
     }
-    // the bound centre is the FLOAT the device will use, so its rounding is inside s_i below
-    const float Cf[3] = {(float)(0.5 * (lo[0] + hi[0])), (float)(0.5 * (lo[1] + hi[1])), (float)(0.5 * (lo[2] + hi[2]))};
+    // centre: the enclosing radius max_i(|c_i - C| + r_i) is convex in C, so a pattern search from the box centre
+    // (axis steps, halved when none improves) finds the near-minimal enclosing sphere, typically 5-15 % smaller than the
+    // box-centred one.  Any centre is valid: R below is measured from the centre actually used.  The bound centre is the
+    // FLOAT the device will use, so its rounding is inside s_i below.
+    double cc[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+    if (ids.size() > 1) {
+        auto reachOf = [&](const double c[3]) {
+            double far = 0.0;
+            for (uint32_t k : ids) {
+                const double dx = sp[k].cx - c[0], dy = sp[k].cy - c[1], dz = sp[k].cz - c[2];
+                far = std::max(far, std::sqrt(dx * dx + dy * dy + dz * dz) + (double)sp[k].r);
+            }
+            return far;
+        };
+        double best = reachOf(cc);
+        double step = 0.25 * best;
+        for (int it = 0; it < 400 && step > 1e-7 * best; ++it) {
+            bool improved = false;
+            for (int ax = 0; ax < 3; ++ax)
+                for (int sgn = -1; sgn <= 1; sgn += 2) {
+                    double t[3] = {cc[0], cc[1], cc[2]};
+                    t[ax] += sgn * step;
+                    const double r = reachOf(t);
+                    if (r < best) {
+                        best = r;
+                        cc[0] = t[0]; cc[1] = t[1]; cc[2] = t[2];
+                        improved = true;
+                    }
+                }
+            if (!improved) step *= 0.5;
+        }
+    }
+    const float Cf[3] = {(float)cc[0], (float)cc[1], (float)cc[2]};
     double R = 0, smax = 0;
     for (uint32_t k : ids) {
         const double dx = sp[k].cx - (double)Cf[0], dy = sp[k].cy - (double)Cf[1], dz = sp[k].cz - (double)Cf[2];
