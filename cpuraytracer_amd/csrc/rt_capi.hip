@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <array>
 #include <vector>
 
 #include "../../include/rt_api.h"
@@ -190,6 +191,103 @@ static float4 BoundOf(const rt_sphere* sp, const std::vector<uint32_t>& ids, flo
     return make_float4(Cf[0], Cf[1], Cf[2], w);
 }
 
+// Enclosing radius of a set of spheres about its near-optimal centre (the same pattern search BoundOf uses).
+static double EnclosingRadius(const rt_sphere* sp, const uint32_t* ids, size_t n) {
+    if (n == 0) return 0.0;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (size_t q = 0; q < n; ++q) {
+        const rt_sphere& s = sp[ids[q]];
+        const double c[3] = {s.cx, s.cy, s.cz};
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], c[a] - (double)s.r);
+            hi[a] = std::max(hi[a], c[a] + (double)s.r);
+        }
+    }
+    double cc[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+    auto reachOf = [&](const double c[3]) {
+        double far = 0.0;
+        for (size_t q = 0; q < n; ++q) {
+            const rt_sphere& s = sp[ids[q]];
+            const double dx = s.cx - c[0], dy = s.cy - c[1], dz = s.cz - c[2];
+            far = std::max(far, std::sqrt(dx * dx + dy * dy + dz * dz) + (double)s.r);
+        }
+        return far;
+    };
+    double best = reachOf(cc);
+    if (n == 1) return best;
+    double step = 0.25 * best;
+    for (int it = 0; it < 60 && step > 1e-4 * best; ++it) {
+        bool improved = false;
+        for (int ax = 0; ax < 3; ++ax)
+            for (int sgn = -1; sgn <= 1; sgn += 2) {
+                double t[3] = {cc[0], cc[1], cc[2]};
+                t[ax] += sgn * step;
+                const double r = reachOf(t);
+                if (r < best) { best = r; cc[0] = t[0]; cc[1] = t[1]; cc[2] = t[2]; improved = true; }
+            }
+        if (!improved) step *= 0.5;
+    }
+    return best;
+}
+
+// Local refinement of the k-d groups: for pairs of spatially neighbouring groups, redistribute their (at most eight)
+// members into two groups of the same sizes when that lowers R1^2 + R2^2 (the filter's candidate count per ray is
+// proportional to the summed squared bound radii).  Groups keep their positions in the list, so the hierarchy above
+// them (consecutive quadruples) stays spatially coherent.  Skipped for very large scenes (upload time).
+static void RefineGroups(const rt_sphere* sp, std::vector<std::vector<uint32_t>>& groups) {
+    const size_t G = groups.size();
+    if (G < 2 || G > 4096) return;
+    std::vector<double> R(G, 0.0);
+    std::vector<std::array<double, 3>> C(G);
+    auto update = [&](size_t g) {
+        R[g] = EnclosingRadius(sp, groups[g].data(), groups[g].size());
+        double c[3] = {0, 0, 0};
+        for (uint32_t k : groups[g]) { c[0] += sp[k].cx; c[1] += sp[k].cy; c[2] += sp[k].cz; }
+        const double inv = groups[g].empty() ? 0.0 : 1.0 / (double)groups[g].size();
+        C[g] = {c[0] * inv, c[1] * inv, c[2] * inv};
+    };
+    for (size_t g = 0; g < G; ++g) update(g);
+    for (int sweep = 0; sweep < 4; ++sweep) {
+        bool any = false;
+        for (size_t g = 0; g < G; ++g) {
+            if (groups[g].size() < 2) continue;  // singletons (big spheres) and padding stay as they are
+            for (size_t h = g + 1; h < G; ++h) {
+                if (groups[h].size() < 2) continue;
+                const double dx = C[g][0] - C[h][0], dy = C[g][1] - C[h][1], dz = C[g][2] - C[h][2];
+                const double reachSum = R[g] + R[h];
+                if (dx * dx + dy * dy + dz * dz > reachSum * reachSum) continue;  // bounds do not even touch
+                const size_t ng = groups[g].size(), nh = groups[h].size(), nt = ng + nh;
+                uint32_t all[8];
+                for (size_t q = 0; q < ng; ++q) all[q] = groups[g][q];
+                for (size_t q = 0; q < nh; ++q) all[ng + q] = groups[h][q];
+                double bestCost = R[g] * R[g] + R[h] * R[h];
+                uint32_t bestMask = 0;
+                for (uint32_t mask = 1; mask < (1u << nt); ++mask) {
+                    if ((size_t)__builtin_popcount(mask) != ng || !(mask & 1u)) continue;  // member 0 stays in g: no mirror splits
+                    uint32_t a[8], b[8];
+                    size_t na = 0, nb = 0;
+                    for (size_t q = 0; q < nt; ++q) ((mask >> q) & 1u ? a[na++] : b[nb++]) = all[q];
+                    const double ra = EnclosingRadius(sp, a, na);
+                    if (ra * ra >= bestCost) continue;
+                    const double rb = EnclosingRadius(sp, b, nb);
+                    const double cost = ra * ra + rb * rb;
+                    if (cost < bestCost * (1.0 - 1e-9)) { bestCost = cost; bestMask = mask; }
+                }
+                if (bestMask != 0 && bestMask != ((1u << ng) - 1u)) {
+                    std::vector<uint32_t> a, b;
+                    for (size_t q = 0; q < nt; ++q) ((bestMask >> q) & 1u ? a : b).push_back(all[q]);
+                    groups[g] = a;
+                    groups[h] = b;
+                    update(g);
+                    update(h);
+                    any = true;
+                }
+            }
+        }
+        if (!any) break;
+    }
+}
+
 static void BuildLayout(const rt_sphere* sp, uint32_t n, uint32_t topMax, SceneLayout& L) {
     std::vector<float> radii(n);
     for (uint32_t k = 0; k < n; ++k) radii[k] = sp[k].r;
@@ -237,6 +335,7 @@ static void BuildLayout(const rt_sphere* sp, uint32_t n, uint32_t topMax, SceneL
         stack.push_back({b + half, e});
         stack.push_back({b, b + half});
     }
+    RefineGroups(sp, groups);
     while (groups.size() & 3u) groups.push_back({});  // whole nodes at the next level; also even for the VALU scan
     L.nGroups = (uint32_t)groups.size();
     const float4 never = make_float4(0.f, 0.f, 0.f, -1e30f);  // r*r = -1e30: discriminant negative for any ray
