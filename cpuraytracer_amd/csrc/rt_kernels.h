@@ -410,7 +410,7 @@ RT_DEV uint32_t split_ray_value(float v) {
 
 // Group operand image for the filter, built once per workgroup: ops[tile][8][64] dwords; lane l of tile t holds
 // matrix row R = l&31: dwords 0-3 = the b chain's two values (-Cx,-Cy | -Cz,1 for l>>5 = 0 | 1) as (hh, ll) pairs,
-// dwords 4-7 = the a*cc chain's (Cx,Cy | Cz,W).  Rows are PERMUTED so that the candidate bitmaps decode with two
+// dwords 4-7 = the a*cc chain's (Cx,Cy | Cz,W) in its three-term form plus the constant slots (below).  Rows are PERMUTED so that the candidate bitmaps decode with two
 // operations: output element e (0..15) of the lane in half h is matrix row (e&3) + 8(e>>2) + 4h, and that row holds
 // group 32 t + 16 h + e.  The image always has an even number of tiles (bitmap words cover two tiles).
 RT_DEV uint32_t mfma_tiles_for(uint32_t nTop) { return (((nTop + 31u) / 32u) + 1u) & ~1u; }
@@ -425,8 +425,16 @@ RT_DEV void build_mfma_operands(const float4* __restrict__ bounds, uint32_t nGro
         uint32_t* o = img + (size_t)t * kOpsPerTile + l;
         split_group_value(h == 0 ? -B.x : -B.z, o[0], o[64]);
         split_group_value(h == 0 ? -B.y : 1.f, o[128], o[192]);
-        split_group_value(h == 0 ? B.x : B.z, o[256], o[320]);
-        split_group_value(h == 0 ? B.y : B.w, o[384], o[448]);
+        // a*cc chain: three cross terms per value (the lo*lo term, <= 2^-18 of the product, is left to the margin) and
+        // two slots that add the per-ray constant a|o|^2 (1 - 2 K eps), carried by the ray side as hi + lo and
+        // multiplied by 1 in the rows' first half only.  Slots: (y0h, y0h, y0l, y1h, y1h, y1l, one, one).
+        uint32_t y0hh, y0ll, y1hh, y1ll;
+        split_group_value(h == 0 ? B.x : B.z, y0hh, y0ll);
+        split_group_value(h == 0 ? B.y : B.w, y1hh, y1ll);
+        o[256] = y0hh;
+        o[320] = (y0ll & 0xffffu) | (y1hh << 16);
+        o[384] = (y1hh & 0xffffu) | (y1ll << 16);
+        o[448] = h == 0 ? 0x3f803f80u : 0u;  // bf16(1.0) twice
     }
 }
 
@@ -436,11 +444,11 @@ RT_DEV void build_mfma_operands(const float4* __restrict__ bounds, uint32_t nGro
 // 1e-4 sqrt(a) (|o| + max(|C|+R)) >= 185x the error bound of b~): then every point of the bound, hence of its member
 // spheres, has t < 0 and the reference accepts no root (bias 0.001, ray-tracing.cpp:52).
 // All three conditions are sign bits: one 3-input bit operation forms "rejected", one v_alignbit appends its sign bit
-// to the lane's bitmap word (five VALU operations per (ray, group) pair, no branches, no LDS).
-RT_DEV void mfma_post(const f32x16& Tb, const f32x16& Tg, float cray, float bthr, uint32_t& rejectedBits) {
+// to the lane's bitmap word (four VALU operations per (ray, group) pair, no branches, no LDS).
+RT_DEV void mfma_post(const f32x16& Tb, const f32x16& Tg, float bthr, uint32_t& rejectedBits) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const float t = Tg[e] + cray;
+        const float t = Tg[e];  // a*cc~ - M: the per-ray constant is part of the contraction
         const float f = __builtin_fmaf(Tb[e], Tb[e], -t);
         const float u = bthr - Tb[e];  // negative <=> centre behind the origin
         const uint32_t rej = __float_as_uint(f) | (__float_as_uint(u) & ~__float_as_uint(t));  // sign bit = rejected
@@ -497,7 +505,10 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
     // Tile 0 (rays of lanes 0-31) takes k = 0,1 from the owner and k = 2,3 from lane+32; tile 1 the other way round:
     // v_permlane32_swap exchanges exactly those halves (upper half of the first register <-> lower half of the second).
     uint32_t b01x = split_ray_value(d.x), b01y = split_ray_value(d.y), b23x = split_ray_value(d.z), b23y = split_ray_value(dO);
-    uint32_t g01x = split_ray_value(gx), g01y = split_ray_value(gy), g23x = split_ray_value(gz), g23y = split_ray_value(a);
+    // a*cc chain, ray side: slots (x0h, x0l, x0h, x1h, x1l, x1h, ch, cl) = dwords (x0h|x0l, x0h|x1h, x1l|x1h, ch|cl)
+    const uint32_t sgx = split_ray_value(gx), sgy = split_ray_value(gy), sgz = split_ray_value(gz), sga = split_ray_value(a);
+    uint32_t g01a = sgx, g01b = __builtin_amdgcn_perm(sgy, sgx, 0x05040100u), g01c = __builtin_amdgcn_alignbit(sgy, sgy, 16);
+    uint32_t g23a = sgz, g23b = __builtin_amdgcn_perm(sga, sgz, 0x05040100u), g23c = __builtin_amdgcn_alignbit(sga, sga, 16);
     uint32_t cr0 = __float_as_uint(cr), cr1 = cr0, bt0 = __float_as_uint(bt), bt1 = bt0;
 #define RT_SWAP32(A, B)                                                        \
     {                                                                          \
@@ -507,16 +518,16 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
     }
     RT_SWAP32(b01x, b23x)  // now b01* = tile 0's operand, b23* = tile 1's
     RT_SWAP32(b01y, b23y)
-    RT_SWAP32(g01x, g23x)
-    RT_SWAP32(g01y, g23y)
+    RT_SWAP32(g01a, g23a)
+    RT_SWAP32(g01b, g23b)
+    RT_SWAP32(g01c, g23c)
     RT_SWAP32(cr0, cr1)  // per-ray scalars: cr0/bt0 belong to the ray of column lane&31 in tile 0, cr1/bt1 in tile 1
     RT_SWAP32(bt0, bt1)
 #undef RT_SWAP32
     const bf16x8 Bb0 = __builtin_bit_cast(bf16x8, (u32x4){b01x, b01x, b01y, b01y});
     const bf16x8 Bb1 = __builtin_bit_cast(bf16x8, (u32x4){b23x, b23x, b23y, b23y});
-    const bf16x8 Bg0 = __builtin_bit_cast(bf16x8, (u32x4){g01x, g01x, g01y, g01y});
-    const bf16x8 Bg1 = __builtin_bit_cast(bf16x8, (u32x4){g23x, g23x, g23y, g23y});
-    const float crT0 = __uint_as_float(cr0), crT1 = __uint_as_float(cr1);
+    const bf16x8 Bg0 = __builtin_bit_cast(bf16x8, (u32x4){g01a, g01b, g01c, split_ray_value(__uint_as_float(cr0))});
+    const bf16x8 Bg1 = __builtin_bit_cast(bf16x8, (u32x4){g23a, g23b, g23c, split_ray_value(__uint_as_float(cr1))});
     const float btT0 = __uint_as_float(bt0), btT1 = __uint_as_float(bt1);
     RT_STAMP(tf0);
     const uint32_t* opsImg = reinterpret_cast<const uint32_t*>(ops);
@@ -534,12 +545,12 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
             {   // ray tile 0 (rays 0..31)
                 const f32x16 Tb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ab, Bb0, zero, 0, 0, 0);
                 const f32x16 Tg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ag, Bg0, zero, 0, 0, 0);
-                mfma_post(Tb, Tg, crT0, btT0, r0);
+                mfma_post(Tb, Tg, btT0, r0);
             }
             {   // ray tile 1 (rays 32..63)
                 const f32x16 Tb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ab, Bb1, zero, 0, 0, 0);
                 const f32x16 Tg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ag, Bg1, zero, 0, 0, 0);
-                mfma_post(Tb, Tg, crT1, btT1, r1);
+                mfma_post(Tb, Tg, btT1, r1);
             }
         }
         if (sp == 0u) {
