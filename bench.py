@@ -169,13 +169,19 @@ def main():
         # assembling the gathered strips is outside the timed region (host side de-interleave for the PPM)
         full = D.assemble([p.cpu().numpy() for p in parts_l], H_IMG, N)
         assert full.shape == (H_IMG, W_IMG, 3)
-        traffic = None
+        traffic, pmc_note = None, "profiles/r01_pmc_summary.json"
         tr_path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if os.path.exists(tr_path):
             try:
                 traffic = json.load(open(tr_path)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        try:  # executed-instruction view of the same kernel from the committed PMC passes (tools/profile_round.sh)
+            d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["derived_trace_kernel"]
+            pmc_note = ("profiles/r01_pmc_summary.json (VALU issue ~%.0f %% busy, matrix cores ~%.0f %%, lane utilisation %.2f, %.3g VALU wave-instructions per launch)"
+                        % (100 * d["valu_issue_busy_estimate"], 100 * d["mfma_busy"], d["valu_lane_utilization"], d["valu_insts_per_launch"]))
+        except Exception:
+            pass
         out = {
             "metric": "Msamples/sec (WxHxspp/s), 1200x800 cover scene spp=128 d=50",
             "value": value, "unit": "Msamples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
@@ -186,15 +192,14 @@ def main():
                                    % (n_spheres, SCENE_SEED, W_IMG, H_IMG, spp, DEPTH, RENDER_SEED, N),
                        "spp_per_gpu": SPP_PER_GPU, "samples_per_step": total_samples,
                        "traversals_per_sample": avg_trav / (W_IMG * rows * spp)},
-            "roofline": {"bound": "valu", "kernel": "rt_trace_kernel<LDS tables, 1024 threads, matrix-core filter>",
+            "roofline": {"bound": "valu", "kernel": "rt_trace_kernel<LDS tables, 1024 threads, matrix-core filter, path cache>",
                          "achieved": achieved_tflops, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / PEAK_VALU_TFLOPS, "traffic": traffic, "launch_ms": avg_ms,
                          "algorithmic": "18 flop x %d spheres x %.0f list scans per launch (SURVEY.md 8d; unfused fp32, peak = 157.3/2)"
                                         % (n_spheres, avg_trav),
                          "note": "frac > 1 is real: ALGORITHMIC flops of exhaustive list scans (SURVEY 8d) over the time of a kernel that "
-                                 "culls (group-bound filter on the matrix cores, exact VALU resolve of the survivors, shadow rays "
-                                 "answered by an exact footprint index). Executed-instruction view: profiles/r01_pmc_summary.json "
-                                 "(VALU issue ~64 % busy, f32 MFMA ~14 %, lane utilisation 0.45)"},
+                                 "culls (split-bf16 group-bound filter on the matrix cores, exact VALU resolve of the survivors, shadow "
+                                 "rays answered by an exact footprint index). Executed-instruction view: " + pmc_note},
             "hbm_read_equivalent": {"bound": "hbm", "achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": achieved_gbs / PEAK_HBM_GBS,
                                     "note": "16 B sphere record x tests / kernel time; served from LDS, so it may exceed the HBM roofline"},

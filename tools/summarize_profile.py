@@ -1,0 +1,66 @@
+"""Turn a tools/profile_round.sh output directory (gpurun_out/<dir>) into the committed summaries under profiles/:
+  <prefix>_bench_line.json, <prefix>_bench_under_rocprof.json, <prefix>_bench_kernel_stats.csv,
+  <prefix>_pmc_summary.json, <prefix>_hbm_traffic.json.
+usage: python tools/summarize_profile.py gpurun_out/profR2 profiles/r01"""
+import csv, glob, json, os, shutil, sys
+src, prefix = sys.argv[1], sys.argv[2]
+
+def last_json_line(path):
+    for ln in reversed(open(path).read().strip().split("\n")):
+        if ln.startswith("{"):
+            return json.loads(ln)
+    return None
+
+bench = last_json_line(os.path.join(src, "bench.json"))
+json.dump(bench, open(prefix + "_bench_line.json", "w"), indent=1)
+json.dump(last_json_line(os.path.join(src, "bench_kt.json")), open(prefix + "_bench_under_rocprof.json", "w"), indent=1)
+ks = glob.glob(os.path.join(src, "kt", "*", "*kernel_stats.csv"))[0]
+shutil.copy(ks, prefix + "_bench_kernel_stats.csv")
+raw = {"trace": {}, "accumulate": {}}
+for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k = "trace" if "rt_trace_kernel" in r["Kernel_Name"] else ("accumulate" if "rt_accumulate" in r["Kernel_Name"] else None)
+        if k:
+            raw[k][r["Counter_Name"]] = raw[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+t = raw["trace"]
+stats = {r["Name"]: r for r in csv.DictReader(open(ks))}
+trace_name = [n for n in stats if "rt_trace_kernel" in n][0]
+launch_ms = float(stats[trace_name]["AverageNs"]) * 1e-6
+# FETCH_SIZE / WRITE_SIZE are in KiB per MI355X_MICROARCH.md; FETCH_SIZE doubled per its gfx950 correction (an upper bound here)
+fetch_b = t.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
+write_b = t.get("WRITE_SIZE", 0.0) * 1024.0
+xcds, simds = 8, 1024
+cyc = t["GRBM_GUI_ACTIVE"] / xcds  # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+CYC_PER_VALU = 2.164  # SIMD cycles per wave-wide VOP2 instruction at the best measured rate (profiles/r01_valu_rate*_microbench.jsonl)
+derived = {
+    "launch_ms_rocprof_avg": launch_ms,
+    "hbm_fetch_bytes": fetch_b, "hbm_write_bytes": write_b, "hbm_bytes_per_launch": fetch_b + write_b,
+    "note_traffic": "WRITE_SIZE is the per-sample buffer: 122.88e6 paths x 12 B = 1.4746e9 B algorithmic. FETCH (doubled per the gfx950 correction, an upper bound here) is noise: tables are staged once per workgroup from L2.",
+    "valu_insts_per_launch": t["SQ_INSTS_VALU"], "salu_insts_per_launch": t["SQ_INSTS_SALU"], "lds_insts_per_launch": t["SQ_INSTS_LDS"],
+    "mfma_insts_per_launch": t["SQ_INSTS_MFMA"],
+    "valu_lane_utilization": t["SQ_THREAD_CYCLES_VALU"] / (t["SQ_INSTS_VALU"] * 64.0),
+    "effective_clock_GHz": cyc / (launch_ms * 1e-3) / 1e9,
+    "valu_issue_busy_estimate": t["SQ_ACTIVE_INST_VALU"] * CYC_PER_VALU / (cyc * simds),
+    "mfma_busy": t["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * simds),
+}
+wc = t["SQ_WAVE_CYCLES"]
+derived["wave_time_split"] = {"issuing": t["SQ_ACTIVE_INST_ANY"] / wc, "wait_inst_issue": t["SQ_WAIT_INST_ANY"] / wc, "wait_cnt_or_barrier": t["SQ_WAIT_ANY"] / wc}
+if "SQ_LDS_BANK_CONFLICT" in t and t.get("SQ_LDS_IDX_ACTIVE"):
+    derived["lds_bank_conflict_frac"] = t["SQ_LDS_BANK_CONFLICT"] / t["SQ_LDS_IDX_ACTIVE"]
+out = {"command": "tools/profile_round.sh: rocprofv3 --kernel-trace --stats (durations) and four separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ group | SQ+MFMA+GRBM group) over python3 bench.py; summarised by tools/summarize_profile.py",
+       "workload": bench["config"]["workload"], "kernel": trace_name, "raw_counters": raw, "derived_trace_kernel": derived}
+prev = prefix + "_pmc_summary.json"
+if os.path.exists(prev):
+    try:
+        old = json.load(open(prev))
+        hist = old.get("history", {})
+        if "derived_trace_kernel" in old and old.get("kernel") != trace_name:
+            d = old["derived_trace_kernel"]
+            hist["before_" + trace_name[:40]] = {k: d.get(k) for k in ("valu_insts_per_launch", "mfma_insts_per_launch", "valu_lane_utilization", "valu_issue_busy_estimate", "mfma_f32_busy", "mfma_busy")}
+        out["history"] = hist
+    except Exception:
+        pass
+json.dump(out, open(prev, "w"), indent=1)
+json.dump({"hbm_bytes_per_launch": fetch_b + write_b, "source": os.path.basename(prev) + " (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; FETCH doubled per the gfx950 correction)"},
+          open(prefix + "_hbm_traffic.json", "w"))
+print(json.dumps(derived, indent=1))
