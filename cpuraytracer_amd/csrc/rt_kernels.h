@@ -369,9 +369,11 @@ RT_DEV void scan_list_deferred(const float4* __restrict__ tab, const uint32_t* _
 // with its own sub-list and register counter (no atomics).  A sub-list that overflows makes its ray
 // fall back to resolving every group (rare; still exact).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr uint32_t kMfmaSlots = 20;                                    // phase-A output entries per ray (gid << 4 | root mask)
+constexpr uint32_t kMfmaSlots = 20;                                    // (VALU scan) per-lane list capacity
+constexpr uint32_t kPoolA = 640;                                        // pooled resolve: (ray, group) items per pass
+constexpr uint32_t kPoolB = 512;                                        // pooled resolve: (ray, sphere) items before a drain
 constexpr uint32_t kStackSlots = 24;                                    // per-lane descent stack (tree scan): 3 * levels + 1 needed
-constexpr uint32_t kWaveListBytes = 64 * kMfmaSlots * 2;                // phase-A lists = 2560 B per wave
+constexpr uint32_t kWaveListBytes = kPoolA * 2 + kPoolB * 2 + 64 * 8;      // item pools + per-ray best keys = 2816 B per wave
 constexpr uint32_t kWaveCandBytes = kWaveListBytes + 64 * kStackSlots * 2;  // + stack = 5632 B per wave
 // K of the filter margins (units of eps * a * G; the host folds the same K into each bound): the matrix-core level needs
 // 101*16 (exact-path rounding, amplified by the member offsets) + ~600 (split-bf16 operands); levels tested on the VALU
@@ -467,6 +469,23 @@ RT_DEV int bound_rejected(const float4 B, V3 o, V3 d, float a, float dO, float m
     const float u = bt - b;
     return __float_as_int(f) | (__float_as_int(u) & ~__float_as_int(t));
 }
+
+// lanes below mine that are set in mask
+RT_DEV uint32_t prefix_count(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// Wave-wide inclusive prefix sum (DPP row shifts + row broadcasts, six VALU instructions, no LDS).
+RT_DEV uint32_t wave_inclusive_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// value of `v` in lane `src` (per-lane source index; every lane of the wave must execute this)
+RT_DEV float lane_fetch(uint32_t src, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src << 2), __float_as_int(v))); }
 
 // One candidate of a ray's 128-bit bitmap (two 64-bit halves: the rows filtered by lanes l&31 and (l&31)+32).  Returns
 // false when none is left.  Leading-zero order; bit N (from the top) of half h is group 16 h + N + (N & 48).
@@ -576,75 +595,101 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
     const uint32_t tot = (uint32_t)(__popcll(cur) + __popcll(nxt));
 #endif
     if (!kTree) {
-        // flat: the top level IS the groups.  Two phases, so that the expensive root code (sqrt + two divides) runs
-        // max-over-lanes(roots per ray) times per scan instead of once or twice per group step:
-        //  A. discriminants of every candidate group; a group with a possible root is appended to the lane's list in
-        //     LDS as gid << 4 | mask (a full list makes the lane evaluate that group's roots at once: rare, exact);
-        //  B. every lane walks its entries and evaluates one candidate sphere per step, recomputing b and disc from
-        //     the same inputs (same operations => same bits as phase A and as the reference).
-        // The closest-hit update is order independent (smaller t, then lower original index).
-        uint16_t* own = waveCand + lane * kMfmaSlots;
-        uint32_t nq = 0;
+        // flat: the top level IS the groups.  The resolve is POOLED over the wave: a ray has 0..20 candidate groups (the
+        // slowest lane of a wave ~9, the average ~3), so instead of every lane walking its own ray's candidates the
+        // wave's (ray, group) pairs go to one work list in LDS and every lane takes the next pair, fetching that ray
+        // from its owner lane (ds_bpermute).  Two pooled phases:
+        //  A. sphere-level filter: the conservative formula on the four one-sphere bounds of the group (13 operations
+        //     per sphere); surviving (ray, sphere) pairs are appended to a second list (ballot + mbcnt offsets);
+        //  B. exact: Sphere::Intersect in the reference's operation order for one (ray, sphere) pair per lane, and the
+        //     closest-hit merge as an LDS 64-bit minimum per ray over the key (t bits, original index, entry):
+        //     smaller t wins, equal t keeps the lower ORIGINAL index, whatever the order of evaluation.
+        uint16_t* poolA = waveCand;
+        uint16_t* poolB = waveCand + kPoolA;
+        unsigned long long* best = reinterpret_cast<unsigned long long*>(waveCand + kPoolA + kPoolB);
+        best[lane] = ~0ull;
+        uint32_t cntB = 0;
+        const uint32_t nMine = (uint32_t)(__popcll(cur) + __popcll(nxt));
+        bool pending = nMine != 0u;
         RT_STAMP(ta0);
-        for (;;) {
-            uint32_t gid = 0;
-            const bool has = next_candidate(cur, nxt, hOff, gid);
-            if (__ballot(has) == 0ull) break;
+        // phase B over the current contents of poolB (wave-uniform count)
+        auto drainB = [&]() {
+            for (uint32_t base = 0; base < cntB; base += kWaveSize) {
+                const uint32_t k = base + lane;
+                const bool has = k < cntB;
+                const uint32_t ent = has ? (uint32_t)poolB[k] : 0u;
+                const uint32_t r = ent >> 10, cand = ent & 1023u;
+                const float rox = lane_fetch(r, o.x), roy = lane_fetch(r, o.y), roz = lane_fetch(r, o.z);
+                const float rdx = lane_fetch(r, d.x), rdy = lane_fetch(r, d.y), rdz = lane_fetch(r, d.z);
+                const float ra = lane_fetch(r, a);
 #ifdef RT_STAMPS
-            dbg[6] += 1;
+                dbg[7] += 1;
 #endif
-            if (has) {
-                // sphere-level filter: the same conservative formula on each member's own bound (13 operations instead
-                // of the 23 of the exact discriminant + root test; phase B decides exactly).  Bit 3-k = sphere k.
+                const float4 S = tab[cand];
+                const float ocx = rox - S.x;
+                const float ocy = roy - S.y;
+                const float ocz = roz - S.z;
+                const float b = (ocx * rdx + ocy * rdy) + ocz * rdz;
+                const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;
+                const float e = b * b - ra * cc;
+                const float sq = __builtin_sqrtf(e);
+                float t = (-b - sq) / ra;               // ray-tracing.cpp:56
+                if (!(t > 0.001f)) t = (-b + sq) / ra;  // :69
+                // `e > 0` is the reference's own test (ray-tracing.cpp:54); `t < inf` is the scan's initial tmin
+                if (has && e > 0.f && t > 0.001f && t < __builtin_inff()) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((orig[cand] << 16) | cand);
+                    __hip_atomic_fetch_min(best + r, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            cntB = 0;
+        };
+        while (__ballot(pending) != 0ull) {
+            // lanes whose items fit into the list this pass: a prefix of the pending lanes
+            const uint32_t incl = wave_inclusive_sum(pending ? nMine : 0u);
+            const bool take = pending && incl <= kPoolA;
+            const uint64_t takeMask = __ballot(take);
+            const uint32_t lastLane = 63u - (uint32_t)__builtin_clzll(takeMask);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)lastLane);
+            if (take) {
+                uint32_t w = incl - nMine, gid = 0;
+                while (next_candidate(cur, nxt, hOff, gid)) poolA[w++] = (uint16_t)(lane << 7 | gid);
+                pending = false;
+            }
+            for (uint32_t base = 0; base < total; base += kWaveSize) {
+#ifdef RT_STAMPS
+                dbg[6] += 1;
+#endif
+                const uint32_t k = base + lane;
+                const bool has = k < total;
+                const uint32_t item = has ? (uint32_t)poolA[k] : 0u;
+                const uint32_t r = item >> 7, gid = item & 127u;
+                const V3 fo = v3(lane_fetch(r, o.x), lane_fetch(r, o.y), lane_fetch(r, o.z));
+                const V3 fd = v3(lane_fetch(r, d.x), lane_fetch(r, d.y), lane_fetch(r, d.z));
+                const float fa = lane_fetch(r, a), fdO = lane_fetch(r, dO), fcr = lane_fetch(r, crLeaf), fbt = lane_fetch(r, bt);
                 const float4* lb = leaf + 4u * gid;
                 uint32_t rb = 0u;
 #pragma unroll
-                for (uint32_t k = 0; k < 4; ++k)
-                    rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(lb[k], o, d, a, dO, m2a, crLeaf, bt), 31);
-                const uint32_t m = ~rb & 15u;
-                if (m != 0u) {
-                    if (__builtin_expect(nq < kMfmaSlots, 1)) {
-                        own[nq] = (uint16_t)(gid << 4 | m);
-                        ++nq;
-                    } else {
-                        resolve_group(tab, orig, 4u * gid, o, d, a, tmin, idx);
-                    }
+                for (uint32_t q = 0; q < 4; ++q)
+                    rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(lb[q], fo, fd, fa, fdO, -2.f * fa, fcr, fbt), 31);
+                const uint32_t m = has ? (~rb & 15u) : 0u;  // bit 3-q = sphere q of the group
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) {
+                    const bool hit = ((m >> (3u - q)) & 1u) != 0u;
+                    const uint64_t hm = __ballot(hit);
+                    if (hit) poolB[cntB + prefix_count(hm)] = (uint16_t)(r << 10 | (4u * gid + q));
+                    cntB += (uint32_t)__popcll(hm);
                 }
+                if (cntB > kPoolB - 4u * kWaveSize) drainB();
             }
         }
-        uint32_t rdPos = 0, ent = 0;
         RT_STAMP(ta1);
         RT_ACC(dbg[4], ta0, ta1);
-        for (;;) {
-#ifdef RT_STAMPS
-            dbg[7] += 1;
-#endif
-            if (ent == 0u && rdPos < nq) {
-                ent = own[rdPos];
-                ++rdPos;
-            }
-            if (__ballot(ent != 0u) == 0ull) break;
-            if (ent != 0u) {
-                const uint32_t k = 3u - (uint32_t)__builtin_ctz(ent & 15u);
-                const uint32_t cand = 4u * (ent >> 4) + k;
-                ent &= ent - 1u;                  // clear the lowest mask bit ...
-                if ((ent & 15u) == 0u) ent = 0u;  // ... and drop the entry once its mask is empty
-                const float4 S = tab[cand];
-                const float ocx = o.x - S.x;
-                const float ocy = o.y - S.y;
-                const float ocz = o.z - S.z;
-                const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
-                const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;
-                const float e = b * b - a * cc;
-                const float sq = __builtin_sqrtf(e);
-                float t = (-b - sq) / a;               // ray-tracing.cpp:56
-                if (!(t > 0.001f)) t = (-b + sq) / a;  // :69
-                // `e > 0` is the reference's own test (ray-tracing.cpp:54); phase A only promised "possible"
-                if (e > 0.f && t > 0.001f && (t < tmin || (t == tmin && idx >= 0 && orig[cand] < orig[idx]))) {
-                    tmin = t;
-                    idx = (int)cand;
-                }
-            }
+        drainB();
+        const unsigned long long mineKey = best[lane];
+        const uint32_t tb = (uint32_t)(mineKey >> 32);
+        if (tb < 0x7f800000u) {
+            tmin = __uint_as_float(tb);
+            idx = (int)(mineKey & 0xffffull);
         }
         RT_STAMP(ta2);
         RT_ACC(dbg[5], ta1, ta2);
@@ -937,10 +982,6 @@ RT_DEV bool shadow_query(const TraceParams& p, const float4* __restrict__ tab, c
     return occluded;
 }
 
-// lanes below mine that are set in mask
-RT_DEV uint32_t prefix_count(uint64_t mask) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
 
 enum : uint32_t { kIdle = 0u, kNeedClosest = 1u, kNeedShadow = 2u };
 
