@@ -513,7 +513,8 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     // dynamic LDS: per-wave candidate regions + the scene tables when they fit + the filter operand image
     const bool tree = ctx->useMfma && tp.n_levels > 1;  // deeper hierarchy: tables stay in global memory (L2)
     const uint32_t topCnt = tp.level_cnt[tp.n_levels - 1];
-    const size_t candBytes = (size_t)wavesPerBlock * (tree ? rtd::kWaveCandBytes : rtd::kWaveListBytes);
+    // the scene constants' slot comes first in the image, then the per-wave regions
+    const size_t candBytes = rtd::kConstBytes + (size_t)wavesPerBlock * (tree ? rtd::kWaveCandBytes : rtd::kWaveListBytes);
     const size_t leafBytes = (size_t)tp.n_padded * 16;  // one-sphere bounds, staged next to the scan table by the flat scan
     const bool flat = !tree && useLds && ctx->useMfma && (candBytes + lds + leafBytes + MfmaOpsBytesFor(topCnt)) <= 160 * 1024;
     const bool ldsTables = useLds && !tree;

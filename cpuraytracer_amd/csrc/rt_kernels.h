@@ -113,6 +113,37 @@ struct TraceParams {
     unsigned long long* counters;  // [0] traversals, [1] segments
 };
 
+// The scene and pass constants the hit processing and the ray generation read, copied once per workgroup into LDS
+// (rt_trace_kernel): as kernel arguments they live in SGPRs for the whole persistent loop (~60 of them, spilled to VGPR
+// lanes and read back with v_readlane at every use, and an SGPR source halves the VOP2 issue rate); from LDS they are
+// short-lived VGPR temporaries.  Member names equal TraceParams' so that the device functions below take either.
+struct SceneConsts {
+    float cam_o[3], cam_x[3], cam_y[3], cam_oip[3];
+    float aperture, focal;
+    float sun_dir[3], sun_rad[3];
+    float sky_emit[3];
+    float exposure;
+    float sg_e1[3], sg_e2[3], sg_u0, sg_v0, sg_inv_cell, sg_p0sq;
+    uint32_t sg_nx, sg_ny, sg_nglobal, sg_enabled;
+    uint32_t W, H, s0, lens_k0;
+    const float2* jitter_tab;
+    const float2* lens_tab;
+};
+constexpr uint32_t kConstBytes = 256;  // LDS reserved for SceneConsts at the start of the dynamic image
+static_assert(sizeof(SceneConsts) <= kConstBytes, "SceneConsts must fit its LDS slot");
+RT_DEV void fill_consts(const TraceParams& p, SceneConsts& k) {
+    for (int i = 0; i < 3; ++i) {
+        k.cam_o[i] = p.cam_o[i]; k.cam_x[i] = p.cam_x[i]; k.cam_y[i] = p.cam_y[i]; k.cam_oip[i] = p.cam_oip[i];
+        k.sun_dir[i] = p.sun_dir[i]; k.sun_rad[i] = p.sun_rad[i]; k.sky_emit[i] = p.sky_emit[i];
+        k.sg_e1[i] = p.sg_e1[i]; k.sg_e2[i] = p.sg_e2[i];
+    }
+    k.aperture = p.aperture; k.focal = p.focal; k.exposure = p.exposure;
+    k.sg_u0 = p.sg_u0; k.sg_v0 = p.sg_v0; k.sg_inv_cell = p.sg_inv_cell; k.sg_p0sq = p.sg_p0sq;
+    k.sg_nx = p.sg_nx; k.sg_ny = p.sg_ny; k.sg_nglobal = p.sg_nglobal; k.sg_enabled = p.sg_enabled;
+    k.W = p.W; k.H = p.H; k.s0 = p.s0; k.lens_k0 = p.lens_k0;
+    k.jitter_tab = p.jitter_tab; k.lens_tab = p.lens_tab;
+}
+
 // --------------------------------------------------------------------------- row sets
 RT_DEV uint32_t rowset_global_row(const rt_rowset& rs, uint32_t lr) {
     const uint32_t lb = lr / rs.block_rows;
@@ -121,7 +152,8 @@ RT_DEV uint32_t rowset_global_row(const rt_rowset& rs, uint32_t lr) {
 }
 
 // Camera::GetRay (camera.cpp:30-48)
-RT_DEV void camera_get_ray(const TraceParams& p, float uvx, float uvy, float lensx, float lensy, V3& origin, V3& dir) {
+template <class P>
+RT_DEV void camera_get_ray(const P& p, float uvx, float uvy, float lensx, float lensy, V3& origin, V3& dir) {
     const V3 camO = v3(p.cam_o[0], p.cam_o[1], p.cam_o[2]);
     const V3 mx = v3(p.cam_x[0], p.cam_x[1], p.cam_x[2]);
     const V3 my = v3(p.cam_y[0], p.cam_y[1], p.cam_y[2]);
@@ -147,7 +179,8 @@ RT_DEV void halton_disk_4_5(uint32_t k, float& lensx, float& lensy) {  // quasi-
     lensx = r * (float)cs;
     lensy = r * (float)sn;
 }
-RT_DEV void gen_primary_ray(const TraceParams& p, uint32_t i, uint32_t j, uint32_t s, V3& origin, V3& dir) {
+template <class P>
+RT_DEV void gen_primary_ray(const P& p, uint32_t i, uint32_t j, uint32_t s, V3& origin, V3& dir) {
     const float xsize = (float)p.W;
     const float ysize = (float)p.H;
     float jx, jy, lensx, lensy;
@@ -871,7 +904,8 @@ RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V
 }
 
 // Emit + DirectionalLight::Shade's unoccluded value (light.cpp:21-40) and Emit + 0 (its value when occluded).
-RT_DEV void shade_value(const TraceParams& p, const Mat& m, V3 tex, V3 pos, V3 nrm, bool wantShade, V3& local, V3& localOccluded) {
+template <class P>
+RT_DEV void shade_value(const P& p, const Mat& m, V3 tex, V3 pos, V3 nrm, bool wantShade, V3& local, V3& localOccluded) {
     V3 emit = v3(0.f, 0.f, 0.f);
     if (m.type == RT_MAT_EMISSIVE) emit = m.luminance * tex;  // material.cpp:172-175; 0 for every other material
     localOccluded = emit + v3(0.f, 0.f, 0.f);  // Shade returns XM_Zero when the sun is occluded (light.cpp:15-18)
@@ -902,8 +936,8 @@ RT_DEV void shade_value(const TraceParams& p, const Mat& m, V3 tex, V3 pos, V3 n
 }
 
 // Scatter, then Emit + Shade with the sun assumed visible (the scan-based shadow path decides later).
-template <class Draws>
-RT_DEV bool scatter_and_shade(const TraceParams& p, const Mat& m, V3 rd, V3 pos, V3 nrm, Draws& draws, V3& atten, V3& outDir,
+template <class P, class Draws>
+RT_DEV bool scatter_and_shade(const P& p, const Mat& m, V3 rd, V3 pos, V3 nrm, Draws& draws, V3& atten, V3& outDir,
                               V3& local, V3& localOccluded) {
     V3 tex;
     const bool scattered = scatter_only(m, rd, nrm, draws, atten, outDir, tex);
@@ -939,7 +973,8 @@ RT_DEV bool sphere_any_hit(const float4 S, V3 o, V3 d, float a) {
 // Two phases, like the closest-hit resolve: first the discriminants of every listed sphere (cheap, uniform), keeping
 // up to four spheres whose roots are possible in a register queue; then roots (sqrt + divides) only for those, until
 // one occludes.  root_possible() is exact, so the answer is the reference's any-hit over the same spheres.
-RT_DEV bool shadow_query(const TraceParams& p, const float4* __restrict__ tab, const uint16_t* __restrict__ cellStart,
+template <class P>
+RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint16_t* __restrict__ cellStart,
                          const uint16_t* __restrict__ entries, const uint16_t* __restrict__ glob, V3 pos, V3 L, float aL) {
     bool occluded = false;
     unsigned long long queue = 0ull;
@@ -1021,9 +1056,12 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     const float* radTab = p.radius;
     const rt_material* matTab = p.mats;
     // per-wave candidate regions first (kWaveCandBytes each; the VALU scan uses the first 2 KiB of its region)
-    uint16_t* candBase = reinterpret_cast<uint16_t*>(smem);
+    // [0, kConstBytes): the scene constants; then the per-wave regions; then the tables
+    SceneConsts* ldsK = reinterpret_cast<SceneConsts*>(smem);
+    if (threadIdx.x == 0) fill_consts(p, *ldsK);
+    uint16_t* candBase = reinterpret_cast<uint16_t*>(smem + kConstBytes / 16);
     constexpr uint32_t kWaveRegion = kScan == 2 ? kWaveCandBytes : kWaveListBytes;  // the descent stack only exists in tree mode
-    float4* tabBase = smem + (kThreads / kWaveSize) * (kWaveRegion / 16);
+    float4* tabBase = smem + kConstBytes / 16 + (kThreads / kWaveSize) * (kWaveRegion / 16);
     const float* mfmaOps = nullptr;
     const float4* treeTab = p.tree;
     const uint16_t* sgCell = p.sg_cell_start;
@@ -1087,7 +1125,9 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     const uint32_t lane = threadIdx.x & (kWaveSize - 1);
     uint16_t* waveCand = candBase + (threadIdx.x / kWaveSize) * (kWaveRegion / 2);
     uint16_t* cand = waveCand + lane;
-    const V3 sunDir = v3(p.sun_dir[0], p.sun_dir[1], p.sun_dir[2]);
+    __syncthreads();  // the constants block (and, above, the staged tables) are visible to every wave from here on
+    const SceneConsts& K = *ldsK;
+    const V3 sunDir = v3(K.sun_dir[0], K.sun_dir[1], K.sun_dir[2]);
     const float aSun = dot3(sunDir, sunDir);  // the `a` of every shadow ray (ray-tracing.cpp:46)
 
     // per-lane path state
@@ -1140,7 +1180,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                         path_coordinates(p, qn, i, j, s);
                         const Rng g = rng_seed(p.seed, j * p.W + i, s);
                         V3 go, gd;
-                        gen_primary_ray(p, i, j, s, go, gd);
+                        gen_primary_ray(K, i, j, s, go, gd);
                         float4* slot = rayCache + 3u * lane;
                         slot[0] = make_float4(go.x, go.y, go.z, gd.x);
                         slot[1] = make_float4(gd.y, gd.z, __uint_as_float(g.s0), __uint_as_float(g.s1));
@@ -1190,7 +1230,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                     uint32_t i, j, s;
                     path_coordinates(p, q, i, j, s);
                     draws.rng = rng_seed(p.seed, j * p.W + i, s);
-                    gen_primary_ray(p, i, j, s, ro, rd);
+                    gen_primary_ray(K, i, j, s, ro, rd);
                     thr = v3(1.f, 1.f, 1.f);
                     rad = v3(0.f, 0.f, 0.f);
                     depth = 0;
@@ -1230,7 +1270,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
             ++nSeg;
             if (idx < 0) {
                 // miss: sky Emissive::Emit (spheres-app.cpp:255)
-                const V3 sky = v3(p.sky_emit[0], p.sky_emit[1], p.sky_emit[2]);
+                const V3 sky = v3(K.sky_emit[0], K.sky_emit[1], K.sky_emit[2]);
                 rad = rad + thr * sky;
                 finished = true;
             } else {
@@ -1246,12 +1286,12 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                 const bool scattered = scatter_only(m, rd, nrm, draws, atten, nextDir, tex);  // Scatter first: it draws (spheres-app.cpp:246)
                 RT_STAMP(th1);
                 const bool cont = (depth < p.max_depth) && scattered;  // spheres-app.cpp:247
-                const bool useIndex = p.sg_enabled && dot3(pos, pos) <= p.sg_p0sq;
+                const bool useIndex = K.sg_enabled && dot3(pos, pos) <= K.sg_p0sq;
                 bool occluded = false;
-                if (useIndex) occluded = shadow_query(p, scanTab, sgCell, sgEntries, sgGlobal, pos, sunDir, aSun);
+                if (useIndex) occluded = shadow_query(K, scanTab, sgCell, sgEntries, sgGlobal, pos, sunDir, aSun);
                 RT_STAMP(th2);
                 // the Blinn-Phong value (two normalisations, two pows) is only needed when the sun is visible or unknown
-                shade_value(p, m, tex, pos, nrm, !occluded, local, localOcc);
+                shade_value(K, m, tex, pos, nrm, !occluded, local, localOcc);
                 RT_STAMP(th3);
 #ifdef RT_STAMPS
                 thA = th0;
@@ -1300,7 +1340,8 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         }
         if (finished) {
             // GetHitColor * exposureAdjustment, spheres-app.cpp:183; one 12-byte store
-            *reinterpret_cast<float3*>(p.samples + (size_t)q * 3) = make_float3(rad.x * p.exposure, rad.y * p.exposure, rad.z * p.exposure);
+            const float expo = K.exposure;
+            *reinterpret_cast<float3*>(p.samples + (size_t)q * 3) = make_float3(rad.x * expo, rad.y * expo, rad.z * expo);
             if (p.trav_out) p.trav_out[q] = pathTrav;
             state = kIdle;
         }
