@@ -684,8 +684,19 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
             const uint32_t lastLane = 63u - (uint32_t)__builtin_clzll(takeMask);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)lastLane);
             if (take) {
-                uint32_t w = incl - nMine, gid = 0;
-                while (next_candidate(cur, nxt, hOff, gid)) poolA[w++] = (uint16_t)(lane << 7 | gid);
+                // one loop per bitmap half (leading-zero order; bit N of half h is group 16 h + N + (N & 48))
+                uint16_t* wp = poolA + (incl - nMine);
+                const uint32_t tag = lane << 7;
+                while (cur != 0ull) {
+                    const uint32_t N = (uint32_t)__builtin_clzll(cur);
+                    cur &= ~(0x8000000000000000ull >> N);
+                    *wp++ = (uint16_t)(tag | (N + (N & 48u)));
+                }
+                while (nxt != 0ull) {
+                    const uint32_t N = (uint32_t)__builtin_clzll(nxt);
+                    nxt &= ~(0x8000000000000000ull >> N);
+                    *wp++ = (uint16_t)(tag | (16u + N + (N & 48u)));
+                }
                 pending = false;
             }
             for (uint32_t base = 0; base < total; base += kWaveSize) {
