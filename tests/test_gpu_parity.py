@@ -392,7 +392,23 @@ def test_random_scenes_differential(hip, oracle, seed, n):
     texture kind, emissive spheres, random cameras with and without depth of field) — per-sample radiance, traversal
     counts and closest hits must equal the oracle's bit for bit.  n <= 512 runs the flat matrix-core filter, larger
     scenes the bounds hierarchy."""
+    _fuzz_case(hip, oracle, seed, n, 1.0, (0.0, 0.0, 0.0))
+
+
+@pytest.mark.parametrize("seed,n,scale,offset", [
+    (21, 400, 1e-3, (0.0, 0.0, 0.0)), (22, 480, 1e3, (0.0, 0.0, 0.0)), (23, 350, 1.0, (2.0e4, -1.0e4, 1.5e4)),
+    (24, 500, 1e2, (3.0e5, 1.0e5, -2.0e5)), (25, 120, 1e-2, (7.0, -3.0, 11.0)), (26, 1500, 10.0, (-4.0e3, 2.0e3, 9.0e3)),
+    (27, 509, 1.0, (0.0, 0.0, 0.0)), (28, 33, 1e3, (1.0e6, 0.0, -1.0e6))])
+def test_random_scenes_scaled_and_translated_differential(hip, oracle, seed, n, scale, offset):
+    """The same differential test with the whole scene (spheres and camera) scaled over six decades and moved far from
+    the origin: the split-bf16 filter's margins are relative to |o|^2 and |C|^2, the shadow index's to P0 and |c|, so
+    this is where a too-small margin would lose a hit."""
+    _fuzz_case(hip, oracle, seed, n, scale, offset)
+
+
+def _fuzz_case(hip, oracle, seed, n, scale, offset):
     rng = np.random.default_rng(1000 + seed)
+    offset = np.asarray(offset, dtype=np.float64)
     extent = rng.choice([3.0, 12.0, 60.0])
     centers = rng.uniform(-extent, extent, size=(n, 3))
     centers[:, 1] = np.abs(centers[:, 1]) * 0.25
@@ -402,8 +418,10 @@ def test_random_scenes_differential(hip, oracle, seed, n):
         radii = np.concatenate([radii, [400.0]])
     n = len(radii)
     types = rng.choice([0, 0, 0, 1, 2, 3], n).astype(np.uint32)
-    sc = _custom_scene(oracle, centers.astype(np.float32), radii.astype(np.float32), types, rng.uniform(-1, 1, 3) * extent * 1.2 + [0, extent * 0.4, 0],
-                       rng.uniform(-0.3, 0.3, 3) * extent, float(rng.uniform(20, 70)), 1.5, aperture=float(rng.choice([0.0, 0.3, 2.0])))
+    cam_o = (rng.uniform(-1, 1, 3) * extent * 1.2 + [0, extent * 0.4, 0]) * scale + offset
+    cam_l = rng.uniform(-0.3, 0.3, 3) * extent * scale + offset
+    sc = _custom_scene(oracle, (centers * scale + offset).astype(np.float32), (radii * scale).astype(np.float32), types, cam_o, cam_l,
+                       float(rng.uniform(20, 70)), 1.5, aperture=float(rng.choice([0.0, 0.3, 2.0])) * scale)
     k255 = np.float32(1) / np.float32(255)
     sc.materials["tex_type"] = rng.integers(0, 2, n)
     sc.materials["tiling"] = rng.choice([4.0, 50.0, 2500.0], n)
