@@ -403,6 +403,7 @@ RT_DEV void scan_list_deferred(const float4* __restrict__ tab, const uint32_t* _
 // fall back to resolving every group (rare; still exact).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr uint32_t kMfmaSlots = 20;                                    // (VALU scan) per-lane list capacity
+constexpr uint32_t kTreeLeafSlots = 22;                                 // hierarchy scan: recorded spheres per lane (64 * 22 * 2 B = the pools' region)
 constexpr uint32_t kPoolA = 640;                                        // pooled resolve: (ray, group) items per pass
 constexpr uint32_t kPoolB = 512;                                        // pooled resolve: (ray, sphere) items before a drain
 constexpr uint32_t kStackSlots = 24;                                    // per-lane descent stack (tree scan): 3 * levels + 1 needed
@@ -742,6 +743,8 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
         // is level << 13 | index.  Internal steps run while ANY lane has an internal node on top of its stack; exact
         // leaf steps run when every live lane is at a leaf, so both kinds of step run with many lanes.
         uint16_t* stack = waveCand + kWaveListBytes / 2 + lane;  // [slot][lane]
+        uint16_t* leafList = waveCand + lane;                    // [slot][lane], kTreeLeafSlots slots
+        uint32_t nq = 0;
         const uint32_t topLevel = nLevels - 1u;
         uint32_t sp = 0;
         for (;;) {
@@ -775,8 +778,48 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                     }
                 }
             } else if (has) {
+                // leaf step: sphere-level conservative filter on the group's one-sphere bounds; survivors go to this
+                // lane's list (the region the flat scan uses for its pools) and are resolved exactly after the descent,
+                // so the root code does not run once per leaf step.  A full list resolves the group on the spot.
                 --sp;
-                resolve_group(tab, orig, 4u * j, o, d, a, tmin, idx);
+                const float4* lb = leaf + 4u * j;
+                uint32_t rb = 0u;
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q)
+                    rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(lb[q], o, d, a, dO, m2a, crLeaf, bt), 31);
+                uint32_t m = ~rb & 15u;  // bit 3-q = entry 4j + q
+                if (m != 0u) {
+                    if (__builtin_expect(nq + 4u <= kTreeLeafSlots, 1)) {
+                        while (m != 0u) {
+                            const uint32_t q = 3u - (31u - (uint32_t)__builtin_clz(m));
+                            m &= ~(8u >> q);
+                            leafList[nq * kWaveSize] = (uint16_t)(4u * j + q);
+                            ++nq;
+                        }
+                    } else {
+                        resolve_group(tab, orig, 4u * j, o, d, a, tmin, idx);
+                    }
+                }
+            }
+        }
+        // exact phase: one recorded sphere per lane per step (reference-order arithmetic, ray-tracing.cpp:44-71)
+        for (uint32_t it = 0; __ballot(it < nq) != 0ull; ++it) {
+            if (it < nq) {
+                const uint32_t cand = leafList[it * kWaveSize];
+                const float4 S = tab[cand];
+                const float ocx = o.x - S.x;
+                const float ocy = o.y - S.y;
+                const float ocz = o.z - S.z;
+                const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
+                const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;
+                const float e = b * b - a * cc;
+                const float sq = __builtin_sqrtf(e);
+                float t = (-b - sq) / a;               // ray-tracing.cpp:56
+                if (!(t > 0.001f)) t = (-b + sq) / a;  // :69
+                if (e > 0.f && t > 0.001f && (t < tmin || (t == tmin && idx >= 0 && orig[cand] < orig[idx]))) {
+                    tmin = t;
+                    idx = (int)cand;
+                }
             }
         }
     }
