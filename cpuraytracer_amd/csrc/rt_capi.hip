@@ -813,6 +813,7 @@ int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, ui
         tp.s0 = s;
         tp.spp_pass = spp;
         tp.total_paths = npix * spp;
+        tp.npix_local = npix;
         tp.max_depth = max_depth;
         tp.seed = seed;
         tp.path_list = nullptr;
@@ -1010,6 +1011,7 @@ int rt_unit_trace(rt_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* ijs, uint
     tp.s0 = 1;
     tp.spp_pass = 1;
     tp.total_paths = n;
+    tp.npix_local = n;
     tp.max_depth = max_depth;
     tp.seed = seed;
     tp.path_list = dIjs.p;

@@ -1,32 +1,35 @@
 // rt_kernels.h — HIP kernels of the render-loop hot path for MI355X (gfx950 / CDNA4).
 //
 // What runs where (reference file:line -> kernel):
-//   GenerateRays            spheres-app.cpp:132-161  -> gen_primary_ray()           (in-register, never materialised)
+//   GenerateRays            spheres-app.cpp:132-161  -> gen_primary_ray()           (64 paths at a time into a per-wave LDS cache)
 //   for_each(par) trace     spheres-app.cpp:177-184  -> rt_trace_kernel             (persistent-threads megakernel)
 //   GetHitColor recursion   spheres-app.cpp:238-257  -> per-lane state machine in rt_trace_kernel
-//   BvhNode/Sphere::Intersect ray-tracing.cpp:42-84,174-214 -> scan_list_mfma() / scan_list_deferred() + resolve_group()
-//   Material::Scatter x3    material.cpp:20-164      -> scatter_and_shade()
-//   DirectionalLight::Shade light.cpp:11-42          -> scatter_and_shade() + the shadow scan
+//   BvhNode/Sphere::Intersect ray-tracing.cpp:42-84,174-214 -> scan_list_mfma() (filter + pooled resolve) / scan_list_deferred()
+//   Material::Scatter x3    material.cpp:20-164      -> scatter_only()
+//   DirectionalLight::Shade light.cpp:11-42          -> shadow_query() (exact footprint index) + shade_value()
 //   hdr[id] += L*exposure   spheres-app.cpp:182-183  -> rt_accumulate_kernel        (ordered in s)
 //   tonemap transform(par)  spheres-app.cpp:196-214  -> rt_resolve_kernel
 //
 // Design (DESIGN.md §5 has the long form and the conservativeness argument):
 //   * one work-item per (pixel, sample) PATH; a wave keeps 64 paths in flight and refills finished
-//     lanes from a global queue by ballot + prefix count, so lanes stay full despite path lengths
-//     of 1..102 list scans;
-//   * a lane is always in one of two states, "needs closest-hit scan" or "needs shadow scan"; both
-//     run the SAME closest-hit search, so every wave iteration is one scan for 64 useful rays (the
-//     shade value is computed before the shadow scan and added after it only if the sun is visible —
-//     same numbers as the reference's order, no state to carry);
+//     lanes (ballot + prefix count) from a per-wave LDS cache of 64 prepared paths that all 64 lanes
+//     generate together from the wave's block of a global queue, so lanes stay full despite path
+//     lengths of 1..51 closest-hit scans;
+//   * shadow rays are answered at the hit by an exact footprint index (spheres binned in the plane
+//     perpendicular to the sun); far hit points fall back to a second scan ("needs shadow scan"
+//     lane state) — the same booleans as the reference's any-hit either way;
 //   * the scan is a conservative FILTER followed by an EXACT resolve.  Spheres are stored in k-d
 //     groups of four with a bounding sphere each; "which ray may hit which group" is a K = 4 dense
-//     contraction evaluated on the matrix cores (v_mfma_f32_32x32x2_f32), survivors are appended to
-//     per-ray candidate lists in LDS, and every lane then evaluates Sphere::Intersect in the
-//     reference's operation order for its own candidates only.  The image equals an exhaustive scan
-//     bit for bit; scene tables, operand image and candidate lists live in LDS (measured: VALU ops
-//     with SGPR sources issue at half rate on gfx950, so scene data must arrive in VGPRs);
+//     contraction evaluated on the matrix cores with split-bf16 operands
+//     (v_mfma_f32_32x32x16_bf16); rejected bits are shifted into register bitmaps, the wave's
+//     (ray, group) pairs are pooled in an LDS work list, filtered per sphere with the same
+//     conservative formula, and the surviving (ray, sphere) pairs evaluate Sphere::Intersect in the
+//     reference's operation order, merged per ray with an LDS 64-bit minimum.  The image equals an
+//     exhaustive scan bit for bit; scene tables, operand image, work lists and scene constants live
+//     in LDS (measured: VALU ops with SGPR sources issue at half rate on gfx950, so scene data must
+//     arrive in VGPRs);
 //   * xoshiro128** state in 4 VGPRs per lane;
-//   * per-path results go to an HBM sample buffer [pixel][s] (12 B each) and are summed in
+//   * per-path results go to an HBM sample buffer [sample][pixel] (12 B each) and are summed in
 //     increasing s by rt_accumulate_kernel: the reference's summation order, bit for bit.
 #pragma once
 
@@ -100,6 +103,7 @@ struct TraceParams {
     uint32_t s0;          // first sample index of this pass (1-based)
     uint32_t spp_pass;    // samples per pixel in this pass
     uint32_t total_paths; // W * local_rows * spp_pass, or the path-list length
+    uint32_t npix_local;  // W * local_rows (the sample buffer is [sample of the pass][local pixel])
     uint32_t max_depth;
     uint64_t seed;
     const uint32_t* path_list;  // optional explicit (i, j, s) triples (unit tests)
@@ -1074,23 +1078,25 @@ RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint1
 
 enum : uint32_t { kIdle = 0u, kNeedClosest = 1u, kNeedShadow = 2u };
 
-// Work-item index -> (column i, global row j, sample s): the explicit path list of the unit tests, or pixel-major
-// order [local pixel][sample of the pass] over the rows of this shard.
-RT_DEV void path_coordinates(const TraceParams& p, uint32_t q, uint32_t& i, uint32_t& j, uint32_t& s) {
+// Work-item index -> (column i, global row j, sample s) and the path's slot in the sample buffer: the explicit path
+// list of the unit tests (slot = index), or pixel-major WORK order [local pixel][sample of the pass] over the rows of
+// this shard (consecutive work-items share a pixel: coherent primary rays) with sample-major STORAGE.
+RT_DEV void path_coordinates(const TraceParams& p, uint32_t q, uint32_t& i, uint32_t& j, uint32_t& s, uint32_t& slot) {
     if (p.path_list) {
         i = p.path_list[3 * q];
         j = p.path_list[3 * q + 1];
         s = p.path_list[3 * q + 2];
+        slot = q;
     } else {
         const uint32_t pl = q / p.spp_pass;
-        s = p.s0 + (q - pl * p.spp_pass);
+        const uint32_t k = q - pl * p.spp_pass;
+        s = p.s0 + k;
         const uint32_t lr = pl / p.W;
         i = pl - lr * p.W;
         j = rowset_global_row(p.rs, lr);
+        slot = k * p.npix_local + pl;  // sample-major storage: rt_accumulate_kernel reads it coalesced
     }
 }
-
-
 
 // ============================================================================ megakernel
 // Persistent threads: every wave loops { refill idle lanes from the queue; one list scan for all
@@ -1189,7 +1195,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     V3 thr = v3(1.f, 1.f, 1.f), rad = v3(0.f, 0.f, 0.f);
     V3 pend = v3(0.f, 0.f, 0.f), nextDir = v3(0.f, 0.f, 0.f);
     StreamDraws draws{Rng{1u, 0u, 0u, 0u}};
-    uint32_t q = 0, depth = 0, state = kIdle, pathTrav = 0;
+    uint32_t q = 0, depth = 0, state = kIdle, pathTrav = 0;  // q = the path's slot in the sample buffer
     bool contAfterShadow = false, pathScattered = false;
     uint32_t nTrav = 0, nSeg = 0;
 
@@ -1230,15 +1236,15 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                     const uint32_t nGen = (blkEnd - blkNext) < (uint32_t)kWaveSize ? (blkEnd - blkNext) : (uint32_t)kWaveSize;
                     if (lane < nGen) {
                         const uint32_t qn = blkNext + lane;
-                        uint32_t i, j, s;
-                        path_coordinates(p, qn, i, j, s);
+                        uint32_t i, j, s, slotn;
+                        path_coordinates(p, qn, i, j, s, slotn);
                         const Rng g = rng_seed(p.seed, j * p.W + i, s);
                         V3 go, gd;
                         gen_primary_ray(K, i, j, s, go, gd);
                         float4* slot = rayCache + 3u * lane;
                         slot[0] = make_float4(go.x, go.y, go.z, gd.x);
                         slot[1] = make_float4(gd.y, gd.z, __uint_as_float(g.s0), __uint_as_float(g.s1));
-                        slot[2] = make_float4(__uint_as_float(g.s2), __uint_as_float(g.s3), __uint_as_float(qn), 0.f);
+                        slot[2] = make_float4(__uint_as_float(g.s2), __uint_as_float(g.s3), __uint_as_float(slotn), 0.f);
                     }
                     blkNext += nGen;
                     cacheCnt = nGen;
@@ -1280,9 +1286,8 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                 const uint32_t want = (uint32_t)__popcll(idleMask);
                 const uint32_t rank = prefix_count(idleMask);
                 if (state == kIdle && rank < avail) {
-                    q = blkNext + rank;
                     uint32_t i, j, s;
-                    path_coordinates(p, q, i, j, s);
+                    path_coordinates(p, blkNext + rank, i, j, s, q);
                     draws.rng = rng_seed(p.seed, j * p.W + i, s);
                     gen_primary_ray(K, i, j, s, ro, rd);
                     thr = v3(1.f, 1.f, 1.f);
@@ -1473,24 +1478,26 @@ __global__ void __launch_bounds__(256) rt_accumulate_kernel(const float* __restr
     const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= npix) return;
     float r = hdr[3 * (size_t)pix], g = hdr[3 * (size_t)pix + 1], b = hdr[3 * (size_t)pix + 2];
-    const float* sp = samples + (size_t)pix * spp * 3;
+    // sample-major buffer: the 64 lanes of a wave read 768 contiguous bytes per sample plane; eight planes in flight,
+    // the adds stay sequential in s
+    const float3* sp = reinterpret_cast<const float3*>(samples) + pix;
     uint32_t s = 0;
-    if ((spp & 3u) == 0u) {
-        // 4 samples = 48 B = three aligned 16-byte loads; the adds stay sequential in s
-        const float4* v = reinterpret_cast<const float4*>(sp);
-        for (; s < spp; s += 4) {
-            const float4 a = v[0], c = v[1], d = v[2];
-            v += 3;
-            r += a.x; g += a.y; b += a.z;
-            r += a.w; g += c.x; b += c.y;
-            r += c.z; g += c.w; b += d.x;
-            r += d.y; g += d.z; b += d.w;
+    for (; s + 8 <= spp; s += 8) {
+        float3 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = sp[(size_t)(s + k) * npix];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            r += v[k].x;
+            g += v[k].y;
+            b += v[k].z;
         }
     }
     for (; s < spp; ++s) {
-        r += sp[3 * s];
-        g += sp[3 * s + 1];
-        b += sp[3 * s + 2];
+        const float3 v = sp[(size_t)s * npix];
+        r += v.x;
+        g += v.y;
+        b += v.z;
     }
     hdr[3 * (size_t)pix] = r;
     hdr[3 * (size_t)pix + 1] = g;
