@@ -324,29 +324,6 @@ RT_DEV void resolve_group(const float4* __restrict__ tab, const uint32_t* __rest
     }
 }
 
-// Phase A of the two-phase resolve: which of the group's four spheres can have an acceptable root for this ray
-// (bit k = sphere g + k).  Same discriminant arithmetic as resolve_group; the roots themselves are evaluated later.
-RT_DEV uint32_t group_root_mask(const float4* __restrict__ tab, uint32_t g, V3 o, V3 d, float a) {
-    const float4 S0 = tab[g], S1 = tab[g + 1], S2 = tab[g + 2], S3 = tab[g + 3];
-    float b0, b1, b2, b3, e0, e1, e2, e3;
-#define RT_DISC(S, B, E)                                               \
-    {                                                                  \
-        const float ocx = o.x - S.x;                                   \
-        const float ocy = o.y - S.y;                                   \
-        const float ocz = o.z - S.z;                                   \
-        B = (ocx * d.x + ocy * d.y) + ocz * d.z;                       \
-        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;  \
-        E = B * B - a * cc;                                            \
-    }
-    RT_DISC(S0, b0, e0)
-    RT_DISC(S1, b1, e1)
-    RT_DISC(S2, b2, e2)
-    RT_DISC(S3, b3, e3)
-#undef RT_DISC
-    return (root_possible(e0, b0) ? 1u : 0u) | (root_possible(e1, b1) ? 2u : 0u) | (root_possible(e2, b2) ? 4u : 0u) |
-           (root_possible(e3, b3) ? 8u : 0u);
-}
-
 // cand: this lane's column of the wave's candidate list in LDS; slot stride is 64 entries.
 RT_DEV void scan_list_deferred(const float4* __restrict__ tab, const uint32_t* __restrict__ orig, uint32_t nPadded, V3 o, V3 d, float& tmin,
                                int& idx, uint16_t* cand) {
@@ -406,13 +383,11 @@ RT_DEV void scan_list_deferred(const float4* __restrict__ tab, const uint32_t* _
 // with its own sub-list and register counter (no atomics).  A sub-list that overflows makes its ray
 // fall back to resolving every group (rare; still exact).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr uint32_t kMfmaSlots = 20;                                    // (VALU scan) per-lane list capacity
-constexpr uint32_t kTreeLeafSlots = 22;                                 // hierarchy scan: recorded spheres per lane (64 * 22 * 2 B = the pools' region)
+constexpr uint32_t kTreeWork = 768, kTreeExact = 576, kTreeReserve = 3 * kMaxLevels;  // hierarchy scan: (ray, node) and (ray, sphere) lists
 constexpr uint32_t kPoolA = 640;                                        // pooled resolve: (ray, group) items per pass
 constexpr uint32_t kPoolB = 512;                                        // pooled resolve: (ray, sphere) items before a drain
-constexpr uint32_t kStackSlots = 24;                                    // per-lane descent stack (tree scan): 3 * levels + 1 needed
 constexpr uint32_t kWaveListBytes = kPoolA * 2 + kPoolB * 2 + 64 * 8;      // item pools + per-ray best keys = 2816 B per wave
-constexpr uint32_t kWaveCandBytes = kWaveListBytes + 64 * kStackSlots * 2;  // + stack = 5632 B per wave
+constexpr uint32_t kWaveCandBytes = kTreeWork * 4 + kTreeExact * 4 + 64 * 8;  // hierarchy scan: 5888 B per wave
 // K of the filter margins (units of eps * a * G; the host folds the same K into each bound): the matrix-core level needs
 // 101*16 (exact-path rounding, amplified by the member offsets) + ~600 (split-bf16 operands); levels tested on the VALU
 // in f32 need 101*16 + 30; a one-sphere bound (offset 0) needs 16 + 30.
@@ -555,7 +530,6 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
     // a dead ray's a*cc~ is made huge so that nothing is ever recorded for it
     const float oo = dot3(o, o);
     const float cr = live ? (a * oo) * (1.f - 2.f * kMarginRel) : 1e30f;
-    const float crValu = (a * oo) * (1.f - 2.f * kMarginKValu * 5.9604645e-8f);  // per-ray margin of the VALU-tested levels
     const float crLeaf = (a * oo) * (1.f - 2.f * kMarginKLeaf * 5.9604645e-8f);  // ... and of the one-sphere bounds
     const float bt = 1e-4f * __builtin_sqrtf(a) * (__builtin_sqrtf(oo) + boundNorm);
     // ray-side operands: values (k = 0,1 | 2,3) of the b chain [dx, dy | dz, d.o] and of the a*cc chain [gx, gy | gz, a].
@@ -743,88 +717,107 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
         RT_STAMP(ta2);
         RT_ACC(dbg[5], ta1, ta2);
     } else {
-        // descent: per-lane depth-first walk of the 4-ary bounds hierarchy below each surviving top node.  A node id
-        // is level << 13 | index.  Internal steps run while ANY lane has an internal node on top of its stack; exact
-        // leaf steps run when every live lane is at a leaf, so both kinds of step run with many lanes.
-        uint16_t* stack = waveCand + kWaveListBytes / 2 + lane;  // [slot][lane]
-        uint16_t* leafList = waveCand + lane;                    // [slot][lane], kTreeLeafSlots slots
-        uint32_t nq = 0;
+        // descent, POOLED over the wave: a LIFO work list of (ray, node) pairs in LDS.  Every round the 64 lanes pop up
+        // to 64 pairs, fetch the pair's ray from its owner lane, test the node's four children with the conservative
+        // formula -- bounds of the level below for an internal node, one-sphere bounds for a group -- and push the
+        // surviving children (ballot + mbcnt offsets): internal survivors back on the work list, sphere survivors on the
+        // exact list, which is drained by the same pooled exact phase as the flat scan (ds_min_u64 merge per ray).  The
+        // walk order is irrelevant to the result.  The list cannot overflow: a round pops at most (room - reserve) / 3
+        // pairs, and the reserve lets a single pair always be expanded down to the leaves (3 slots per level).
+        uint32_t* work = reinterpret_cast<uint32_t*>(waveCand);               // kTreeWork entries: ray << 20 | level << 16 | index
+        uint32_t* exact = work + kTreeWork;                                   // kTreeExact entries: ray << 16 | scan entry
+        unsigned long long* best = reinterpret_cast<unsigned long long*>(exact + kTreeExact);
+        best[lane] = ~0ull;
         const uint32_t topLevel = nLevels - 1u;
-        uint32_t sp = 0;
-        for (;;) {
-            if (sp == 0) {
-                uint32_t t = 0;
-                if (next_candidate(cur, nxt, hOff, t)) {
-                    stack[0] = (uint16_t)((topLevel << 13) | t);
-                    sp = 1;
+        const float aoo = a * oo;
+        uint32_t nWork = 0, nExact = 0;
+        auto drainExact = [&]() {
+            for (uint32_t base = 0; base < nExact; base += kWaveSize) {
+                const uint32_t k = base + lane;
+                const bool has = k < nExact;
+                const uint32_t ent = has ? exact[k] : 0u;
+                const uint32_t r = ent >> 16, cand = ent & 0xffffu;
+                const float rox = lane_fetch(r, o.x), roy = lane_fetch(r, o.y), roz = lane_fetch(r, o.z);
+                const float rdx = lane_fetch(r, d.x), rdy = lane_fetch(r, d.y), rdz = lane_fetch(r, d.z);
+                const float ra = lane_fetch(r, a);
+                const float4 S = tab[cand];
+                const float ocx = rox - S.x;
+                const float ocy = roy - S.y;
+                const float ocz = roz - S.z;
+                const float b = (ocx * rdx + ocy * rdy) + ocz * rdz;
+                const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;
+                const float e = b * b - ra * cc;
+                const float sq = __builtin_sqrtf(e);
+                float t = (-b - sq) / ra;               // ray-tracing.cpp:56
+                if (!(t > 0.001f)) t = (-b + sq) / ra;  // :69
+                if (has && e > 0.f && t > 0.001f && t < __builtin_inff()) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((orig[cand] << 16) | cand);
+                    __hip_atomic_fetch_min(best + r, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-            const bool has = sp > 0;
-            if (__ballot(has) == 0ull) break;
-            const uint32_t node = has ? stack[(sp - 1u) * kWaveSize] : 0u;
-            const uint32_t lvl = node >> 13, j = node & 0x1fffu;
-            const bool internal = has && lvl > 0u;
-            if (__ballot(internal) != 0ull) {
-                if (internal) {
-                    --sp;
-                    const uint32_t cl = lvl - 1u;
-                    uint32_t off = levelOff[0];
+            nExact = 0;
+        };
+        for (;;) {
+            // feed: when fewer than a round's worth of pairs is listed, every lane with top-level candidates left adds one
+            if (nWork < (uint32_t)kWaveSize) {
+                uint32_t t = 0;
+                const bool add = next_candidate(cur, nxt, hOff, t);
+                const uint64_t am = __ballot(add);
+                if (add) work[nWork + prefix_count(am)] = lane << 20 | topLevel << 16 | t;
+                nWork += (uint32_t)__popcll(am);
+            }
+            if (nWork == 0u) break;
+            const uint32_t room = nWork < kTreeWork - kTreeReserve ? kTreeWork - kTreeReserve - nWork : 0u;
+            uint32_t np = room / 3u;
+            np = np < 1u ? 1u : np;
+            np = np > (uint32_t)kWaveSize ? (uint32_t)kWaveSize : np;
+            np = np > nWork ? nWork : np;
+            const bool has = lane < np;
+            const uint32_t ent = has ? work[nWork - 1u - lane] : 0u;
+            nWork -= np;
+            const uint32_t r = ent >> 20, lvl = (ent >> 16) & 7u, j = ent & 0xffffu;
+            const V3 fo = v3(lane_fetch(r, o.x), lane_fetch(r, o.y), lane_fetch(r, o.z));
+            const V3 fd = v3(lane_fetch(r, d.x), lane_fetch(r, d.y), lane_fetch(r, d.z));
+            const float fa = lane_fetch(r, a), fdO = lane_fetch(r, dO), faoo = lane_fetch(r, aoo), fbt = lane_fetch(r, bt);
+            const bool internal = lvl > 0u;
+            float4 B0, B1, B2, B3;
+            if (internal) {
+                const uint32_t cl = lvl - 1u;
+                uint32_t off = levelOff[0];
 #pragma unroll
-                    for (uint32_t k = 1; k < kMaxLevels - 1; ++k) off = cl == k ? levelOff[k] : off;
-                    const float4* ch = tree + off + 4u * j;
-#pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q) {
-                        const int rej = bound_rejected(ch[q], o, d, a, dO, m2a, crValu, bt);
-                        if (rej >= 0) {
-                            stack[sp * kWaveSize] = (uint16_t)((cl << 13) | (4u * j + q));
-                            ++sp;
-                        }
-                    }
-                }
-            } else if (has) {
-                // leaf step: sphere-level conservative filter on the group's one-sphere bounds; survivors go to this
-                // lane's list (the region the flat scan uses for its pools) and are resolved exactly after the descent,
-                // so the root code does not run once per leaf step.  A full list resolves the group on the spot.
-                --sp;
+                for (uint32_t k = 1; k < kMaxLevels - 1; ++k) off = cl == k ? levelOff[k] : off;
+                const float4* ch = tree + off + 4u * j;
+                B0 = ch[0]; B1 = ch[1]; B2 = ch[2]; B3 = ch[3];
+            } else {
                 const float4* lb = leaf + 4u * j;
-                uint32_t rb = 0u;
+                B0 = lb[0]; B1 = lb[1]; B2 = lb[2]; B3 = lb[3];
+            }
+            const float fcr = faoo * (internal ? (1.f - 2.f * kMarginKValu * 5.9604645e-8f) : (1.f - 2.f * kMarginKLeaf * 5.9604645e-8f));
+            const float fm2a = -2.f * fa;
+            uint32_t rb = 0u;
+            rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B0, fo, fd, fa, fdO, fm2a, fcr, fbt), 31);
+            rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B1, fo, fd, fa, fdO, fm2a, fcr, fbt), 31);
+            rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B2, fo, fd, fa, fdO, fm2a, fcr, fbt), 31);
+            rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B3, fo, fd, fa, fdO, fm2a, fcr, fbt), 31);
+            const uint32_t m = has ? (~rb & 15u) : 0u;  // bit 3-q = child 4j + q
+            if (nExact > kTreeExact - 4u * kWaveSize) drainExact();
 #pragma unroll
-                for (uint32_t q = 0; q < 4; ++q)
-                    rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(lb[q], o, d, a, dO, m2a, crLeaf, bt), 31);
-                uint32_t m = ~rb & 15u;  // bit 3-q = entry 4j + q
-                if (m != 0u) {
-                    if (__builtin_expect(nq + 4u <= kTreeLeafSlots, 1)) {
-                        while (m != 0u) {
-                            const uint32_t q = 3u - (31u - (uint32_t)__builtin_clz(m));
-                            m &= ~(8u >> q);
-                            leafList[nq * kWaveSize] = (uint16_t)(4u * j + q);
-                            ++nq;
-                        }
-                    } else {
-                        resolve_group(tab, orig, 4u * j, o, d, a, tmin, idx);
-                    }
-                }
+            for (uint32_t q = 0; q < 4; ++q) {
+                const bool hit = ((m >> (3u - q)) & 1u) != 0u;
+                const uint64_t wm = __ballot(hit && internal);
+                const uint64_t em = __ballot(hit && !internal);
+                if (hit && internal) work[nWork + prefix_count(wm)] = r << 20 | (lvl - 1u) << 16 | (4u * j + q);
+                if (hit && !internal) exact[nExact + prefix_count(em)] = r << 16 | (4u * j + q);
+                nWork += (uint32_t)__popcll(wm);
+                nExact += (uint32_t)__popcll(em);
             }
         }
-        // exact phase: one recorded sphere per lane per step (reference-order arithmetic, ray-tracing.cpp:44-71)
-        for (uint32_t it = 0; __ballot(it < nq) != 0ull; ++it) {
-            if (it < nq) {
-                const uint32_t cand = leafList[it * kWaveSize];
-                const float4 S = tab[cand];
-                const float ocx = o.x - S.x;
-                const float ocy = o.y - S.y;
-                const float ocz = o.z - S.z;
-                const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
-                const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;
-                const float e = b * b - a * cc;
-                const float sq = __builtin_sqrtf(e);
-                float t = (-b - sq) / a;               // ray-tracing.cpp:56
-                if (!(t > 0.001f)) t = (-b + sq) / a;  // :69
-                if (e > 0.f && t > 0.001f && (t < tmin || (t == tmin && idx >= 0 && orig[cand] < orig[idx]))) {
-                    tmin = t;
-                    idx = (int)cand;
-                }
-            }
+        drainExact();
+        const unsigned long long mineKey = best[lane];
+        const uint32_t tb = (uint32_t)(mineKey >> 32);
+        if (tb < 0x7f800000u) {
+            tmin = __uint_as_float(tb);
+            idx = (int)(mineKey & 0xffffull);
         }
     }
 #ifdef RT_STAMPS
