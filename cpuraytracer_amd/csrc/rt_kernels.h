@@ -29,7 +29,7 @@
 //     in LDS (measured: VALU ops with SGPR sources issue at half rate on gfx950, so scene data must
 //     arrive in VGPRs);
 //   * xoshiro128** state in 4 VGPRs per lane;
-//   * per-path results go to an HBM sample buffer [sample][pixel] (12 B each) and are summed in
+//   * per-path results go to an HBM sample buffer [tile of 64 pixels][sample][pixel] (12 B each) and are summed in
 //     increasing s by rt_accumulate_kernel: the reference's summation order, bit for bit.
 #pragma once
 
@@ -1072,8 +1072,7 @@ RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint1
 enum : uint32_t { kIdle = 0u, kNeedClosest = 1u, kNeedShadow = 2u };
 
 // Work-item index -> (column i, global row j, sample s) and the path's slot in the sample buffer: the explicit path
-// list of the unit tests (slot = index), or pixel-major WORK order [local pixel][sample of the pass] over the rows of
-// this shard (consecutive work-items share a pixel: coherent primary rays) with sample-major STORAGE.
+// list of the unit tests, or the tiled order below over the rows of this shard.  slot = index either way.
 RT_DEV void path_coordinates(const TraceParams& p, uint32_t q, uint32_t& i, uint32_t& j, uint32_t& s, uint32_t& slot) {
     if (p.path_list) {
         i = p.path_list[3 * q];
@@ -1081,13 +1080,28 @@ RT_DEV void path_coordinates(const TraceParams& p, uint32_t q, uint32_t& i, uint
         s = p.path_list[3 * q + 2];
         slot = q;
     } else {
-        const uint32_t pl = q / p.spp_pass;
-        const uint32_t k = q - pl * p.spp_pass;
+        // work order = storage order = [tile of 64 local pixels][sample of the pass][pixel in tile] (the last tile is as
+        // wide as the pixels left): a wave's block of 256 consecutive work-items is four sample planes of one tile, so
+        // its 12-byte results fill whole cache lines, and rt_accumulate_kernel reads 768 contiguous bytes per plane
+        const uint32_t tileSpan = 64u * p.spp_pass;
+        const uint32_t nFull = p.npix_local >> 6;
+        const uint32_t tile = q / tileSpan;
+        uint32_t pl, k;
+        if (tile < nFull) {
+            const uint32_t rem = q - tile * tileSpan;
+            k = rem >> 6;
+            pl = (tile << 6) + (rem & 63u);
+        } else {
+            const uint32_t rem = q - nFull * tileSpan;
+            const uint32_t wl = p.npix_local - (nFull << 6);
+            k = rem / wl;
+            pl = (nFull << 6) + (rem - k * wl);
+        }
         s = p.s0 + k;
         const uint32_t lr = pl / p.W;
         i = pl - lr * p.W;
         j = rowset_global_row(p.rs, lr);
-        slot = k * p.npix_local + pl;  // sample-major storage: rt_accumulate_kernel reads it coalesced
+        slot = q;
     }
 }
 
@@ -1471,14 +1485,16 @@ __global__ void __launch_bounds__(256) rt_accumulate_kernel(const float* __restr
     const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= npix) return;
     float r = hdr[3 * (size_t)pix], g = hdr[3 * (size_t)pix + 1], b = hdr[3 * (size_t)pix + 2];
-    // sample-major buffer: the 64 lanes of a wave read 768 contiguous bytes per sample plane; eight planes in flight,
-    // the adds stay sequential in s
-    const float3* sp = reinterpret_cast<const float3*>(samples) + pix;
+    // tiled buffer [tile of 64 pixels][sample][pixel in tile] (path_coordinates): the 64 lanes of a wave read 768
+    // contiguous bytes per sample plane; eight planes in flight, the adds stay sequential in s
+    const uint32_t nFull = npix >> 6, tile = pix >> 6;
+    const uint32_t stride = tile < nFull ? 64u : npix - (nFull << 6);
+    const float3* sp = reinterpret_cast<const float3*>(samples) + (size_t)tile * 64u * spp + (pix - (tile << 6));
     uint32_t s = 0;
     for (; s + 8 <= spp; s += 8) {
         float3 v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = sp[(size_t)(s + k) * npix];
+        for (int k = 0; k < 8; ++k) v[k] = sp[(size_t)(s + k) * stride];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             r += v[k].x;
@@ -1487,7 +1503,7 @@ __global__ void __launch_bounds__(256) rt_accumulate_kernel(const float* __restr
         }
     }
     for (; s < spp; ++s) {
-        const float3 v = sp[(size_t)s * npix];
+        const float3 v = sp[(size_t)s * stride];
         r += v.x;
         g += v.y;
         b += v.z;
