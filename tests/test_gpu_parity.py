@@ -207,6 +207,9 @@ def test_headline_config_per_sample_golden(hip, scenes_mod):
     ("cover", 160, 104, 4, 50, -1.0),    # C2 geometry, small
     ("cover", 160, 90, 3, 50, 2.0),      # C4: depth-of-field camera, aperture 2.0
     ("three", 37, 23, 6, 3, 0.5),        # ragged sizes, shallow depth
+    ("three", 1, 1, 3, 8, -1.0),         # one pixel: a single partial tile of the sample buffer
+    ("three", 65, 1, 2, 8, -1.0),        # one full 64-pixel tile + a one-pixel tile
+    ("cover", 129, 3, 130, 50, -1.0),    # more samples than a queue block per pixel row, ragged tiles
 ])
 def test_image_parity_with_oracle(hip, oracle, scenes_mod, name, W, H, s1, depth, ap):
     sc = scenes_mod.build_scene(name, 1, W, H, aperture=ap)
