@@ -100,6 +100,7 @@ struct rt_ctx {
     bool useMfma = true;  // matrix-core pre-filter for the list scan (RT_SCAN=valu disables)
     bool matsInLds = true;   // RT_MATS_LDS=0 leaves the material table in global memory (frees 48 B/sphere of LDS)
     bool useRayCache = true;
+    bool treeInLds = true;      // RT_TREE_LDS=0: the hierarchy's bounds are read through L2
     uint32_t treeTop = 128;  // largest top level the matrix-core filter takes (4 tiles of 32); RT_TREE_TOP overrides
     bool forceGlobal = false;
 };
@@ -522,7 +523,7 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     if (candBytes + lds + leafBytes + MfmaOpsBytesFor(topCnt) + sgBytes > 160 * 1024) sgBytes = 0;  // index stays in global memory (L2)
     tp.sg_in_lds = sgBytes ? 1u : 0u;
     size_t treeBytes = tree ? (size_t)(tp.level_off[tp.n_levels - 1] + topCnt) * 16 : 0;
-    if (candBytes + MfmaOpsBytesFor(topCnt) + treeBytes > 160 * 1024) treeBytes = 0;
+    if (!ctx->treeInLds || candBytes + MfmaOpsBytesFor(topCnt) + treeBytes > 160 * 1024) treeBytes = 0;
     tp.tree_in_lds = treeBytes ? 1u : 0u;
     size_t ldsBytes = candBytes + (ldsTables ? lds : 0) + (flat ? leafBytes : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0) + sgBytes + treeBytes;
     // per-wave caches of prepared paths go last, when there is room left (RT_RAY_CACHE=0 disables them)
@@ -602,6 +603,7 @@ int rt_create(int device_ordinal, rt_ctx** out) {
         ctx->matsInLds = EnvU32("RT_MATS_LDS", 1) != 0;
         ctx->useShadowGrid = EnvU32("RT_SHADOW_GRID", 1) != 0;
         ctx->useRayCache = EnvU32("RT_RAY_CACHE", 1) != 0;
+        ctx->treeInLds = EnvU32("RT_TREE_LDS", 1) != 0;
         ctx->treeTop = EnvU32("RT_TREE_TOP", 128);
         if (ctx->treeTop < 4 || ctx->treeTop > 128) ctx->treeTop = 128;
     }
