@@ -493,7 +493,8 @@ static void BuildShadowGrid(const rt_sphere* sp, const SceneLayout& L, const flo
 }
 
 static size_t LdsBytesFor(uint32_t n, uint32_t nPadded, bool mats) {
-    return (size_t)nPadded * (16 + 4) + (mats ? (size_t)n * 48 : 0) + (size_t)((n + 3) / 4) * 16;
+    (void)n;  // radius and material tables are stored per scan entry (clustered order), like the scan table
+    return (size_t)nPadded * (16 + 4) + (mats ? (size_t)nPadded * 48 : 0) + (size_t)nPadded * 4;
 }
 static size_t MfmaOpsBytesFor(uint32_t nGroups) { return (size_t)rtd::mfma_tiles_for(nGroups) * rtd::kOpsPerTile * 4; }
 
@@ -675,17 +676,25 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     if ((rc = ctx->orig.Reserve(nPad)) != RT_OK) return rc;
     if ((rc = ctx->tree.Reserve(L.tree.size())) != RT_OK) return rc;
     if ((rc = ctx->leaf.Reserve(nPad)) != RT_OK) return rc;
-    if ((rc = ctx->radius.Reserve(n)) != RT_OK) return rc;
-    if ((rc = ctx->mats.Reserve(n)) != RT_OK) return rc;
-    std::vector<float> rad(n);
-    for (uint32_t k = 0; k < n; ++k) rad[k] = spheres[k].r;
+    if ((rc = ctx->radius.Reserve(nPad)) != RT_OK) return rc;
+    if ((rc = ctx->mats.Reserve(nPad)) != RT_OK) return rc;
+    // radius and material of every scan entry, in clustered order: the hit processing indexes them with the entry it
+    // found, with no detour through the original index (one dependent load less; material i still belongs to sphere i)
+    std::vector<float> rad(nPad, 0.f);
+    std::vector<rt_material> matc(nPad);
+    std::memset(matc.data(), 0, nPad * sizeof(rt_material));
+    for (uint32_t e = 0; e < nPad; ++e) {
+        if (L.orig[e] == 0xffffffffu) continue;
+        rad[e] = spheres[L.orig[e]].r;
+        matc[e] = materials[L.orig[e]];
+    }
     RT_HIP(hipStreamSynchronize(ctx->stream));
     RT_HIP(hipMemcpy(ctx->scan.ptr, L.scan.data(), nPad * sizeof(float4), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->orig.ptr, L.orig.data(), nPad * sizeof(uint32_t), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->tree.ptr, L.tree.data(), L.tree.size() * sizeof(float4), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->leaf.ptr, L.leaf.data(), nPad * sizeof(float4), hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(ctx->radius.ptr, rad.data(), n * sizeof(float), hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(ctx->mats.ptr, materials, n * sizeof(rt_material), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->radius.ptr, rad.data(), nPad * sizeof(float), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->mats.ptr, matc.data(), nPad * sizeof(rt_material), hipMemcpyHostToDevice));
 
     ShadowGrid SG;
     if (ctx->useShadowGrid) BuildShadowGrid(spheres, L, sun->direction, SG);

@@ -78,8 +78,8 @@ struct TraceParams {
     uint32_t level_off[kMaxLevels], level_cnt[kMaxLevels];
     uint32_t n_levels;
     uint32_t tree_in_lds;      // tree mode: stage every level of bounds into LDS (else the descent reads them through L2)
-    const float* radius;       // [n] by original index
-    const rt_material* mats;   // [n] by original index
+    const float* radius;       // [n_padded] per scan entry (clustered order)
+    const rt_material* mats;   // [n_padded] per scan entry: material i of the reference belongs to sphere i = orig[entry]
     uint32_t n;                // real spheres
     uint32_t n_groups;         // groups of four entries (even)
     uint32_t mats_in_lds;      // stage the material table into LDS (else it is read through L2)
@@ -1144,7 +1144,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         float4* ldsLeaf = ldsScan + p.n_padded;
         uint32_t* ldsOrig = reinterpret_cast<uint32_t*>(ldsLeaf + (kScan == 1 ? p.n_padded : 0u));
         float4* ldsMat = reinterpret_cast<float4*>(ldsOrig + p.n_padded);  // n_padded is a multiple of 4
-        const uint32_t nMatLds = p.mats_in_lds ? p.n : 0u;
+        const uint32_t nMatLds = p.mats_in_lds ? p.n_padded : 0u;
         float* ldsRad = reinterpret_cast<float*>(ldsMat + (size_t)nMatLds * 3);
         const float4* gMat = reinterpret_cast<const float4*>(p.mats);
         for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) {
@@ -1153,9 +1153,9 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
             if (kScan == 1) ldsLeaf[k] = p.leaf[k];
         }
         for (uint32_t k = threadIdx.x; k < nMatLds * 3; k += blockDim.x) ldsMat[k] = gMat[k];
-        for (uint32_t k = threadIdx.x; k < p.n; k += blockDim.x) ldsRad[k] = p.radius[k];
+        for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) ldsRad[k] = p.radius[k];
         if (kMfma) {
-            float* ldsOps = ldsRad + ((p.n + 3u) & ~3u);
+            float* ldsOps = ldsRad + p.n_padded;  // a multiple of 4
             build_mfma_operands(p.tree + p.level_off[topLevel], nTop, nTiles, ldsOps, threadIdx.x, blockDim.x);
             mfmaOps = ldsOps;
             if (p.sg_enabled && p.sg_in_lds) {  // shadow index after the operand image
@@ -1341,9 +1341,8 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                 finished = true;
             } else {
                 const float4 S = scanTab[idx];
-                const uint32_t oi = origTab[idx];  // original list index: material i belongs to sphere i
-                const float radius = radTab[oi];
-                const Mat m = load_material(matTab, (int)oi);
+                const float radius = radTab[idx];  // radius and material tables are in scan-entry (clustered) order
+                const Mat m = load_material(matTab, idx);
                 const V3 center = v3(S.x, S.y, S.z);
                 const V3 pos = tmin * rd + ro;          // XMVectorMultiplyAdd(t, dir, origin), ray-tracing.cpp:57
                 const V3 nrm = (pos - center) / radius;  // ray-tracing.cpp:58
@@ -1568,7 +1567,7 @@ __global__ void k_unit_closest(const TraceParams p, const float* rays, uint32_t 
     if (idx >= 0) {
         const float4 S = p.scan[idx];
         const V3 pos = tmin * d + o;
-        const V3 nrm = (pos - v3(S.x, S.y, S.z)) / p.radius[oidx];
+        const V3 nrm = (pos - v3(S.x, S.y, S.z)) / p.radius[idx];
         w[0] = tmin;
         w[2] = pos.x; w[3] = pos.y; w[4] = pos.z;
         w[5] = nrm.x; w[6] = nrm.y; w[7] = nrm.z;
