@@ -118,7 +118,7 @@ static uint32_t RowsetLocalRows(rt_rowset rs) {
 }
 
 // ---------------------------------------------------------------------------------- scene layout
-// Clustered storage for the scan (rt_kernels.h): spheres split by a k-d median tree into groups of four, unusually
+// Clustered storage for the scan (rt_scan.h): spheres split by a k-d median tree into groups of four, unusually
 // large spheres alone, every group with a conservative bounding sphere for the matrix-core filter.
 struct SceneLayout {
     std::vector<float4> scan;     // 4 * nGroups + 4 entries
@@ -134,7 +134,7 @@ struct SceneLayout {
 // Conservative bounding sphere of a set of spheres, in the filter's (C, |C|^2 - Rf^2) form.
 static float4 BoundOf(const rt_sphere* sp, const std::vector<uint32_t>& ids, float* normOut, float marginK) {
     if (ids.empty()) return make_float4(0.f, 0.f, 0.f, 1e30f);  // never a candidate
-    const double kEps = (double)marginK * 5.9604644775390625e-08;  // K * eps: K is that of the unit testing this bound (rt_kernels.h)
+    const double kEps = (double)marginK * 5.9604644775390625e-08;  // K * eps: K is that of the unit testing this bound (rt_scan.h)
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (uint32_t k : ids) {
         const double c[3] = {sp[k].cx, sp[k].cy, sp[k].cz};
@@ -375,7 +375,7 @@ static void BuildLayout(const rt_sphere* sp, uint32_t n, uint32_t topMax, SceneL
     }
 }
 // ---------------------------------------------------------------------------------- shadow index
-// Footprints of the spheres in the plane perpendicular to the sun, binned into a uniform grid (rt_kernels.h
+// Footprints of the spheres in the plane perpendicular to the sun, binned into a uniform grid (rt_shade.h
 // shadow_query).  Conservative by construction: footprint radius rho = sqrt(r^2 + 64 eps (2 P0^2 + 2|c|^2 + r^2))
 // (1 + 1e-4) + 1e-5 (P0 + |c| + 1) covers the reference test's own rounding for hit points with |p| <= P0 (E/a <= 16
 // eps (...), 4x safety) and the rounding of the float projection; a sphere is listed in every cell its footprint's
@@ -1120,7 +1120,7 @@ int rt_unit_layout(const rt_sphere* spheres, uint32_t n, uint32_t cap_groups, ui
 }
 
 #ifdef RT_STAMPS
-// Diagnostic build only: read and clear the section clocks (see rt_kernels.h g_dbg).
+// Diagnostic build only: read and clear the section clocks (see rt_params.h g_dbg).
 int rt_debug_stamps(rt_ctx* ctx, unsigned long long out[20]) {
     if (!ctx || !out) return Fail(RT_ERR_INVALID_ARG, "rt_debug_stamps: invalid argument");
     RT_HIP(hipSetDevice(ctx->device));

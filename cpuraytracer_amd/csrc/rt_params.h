@@ -1,0 +1,180 @@
+// rt_params.h — launch parameters, LDS-resident scene constants, row-set arithmetic and primary-ray generation of the
+// render-loop kernels (see rt_kernels.h for the map from reference functions to kernels).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_api.h"
+#include "rt_device_math.h"
+
+namespace rtd {
+
+
+// Diagnostic build only (-DRT_STAMPS): per-section shader-clock sums go to g_dbg[], which no kernel reads.
+// The shipped library is built without it.
+#ifdef RT_STAMPS
+static __device__ unsigned long long g_dbg[20];  // refill, scan, transitions, iterations, filter, resolve, resolve items, max items,
+                                                 // phase A cycles, phase B cycles, A iterations, B iterations, scatter, shadow query, shade, -
+RT_DEV unsigned long long rt_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define RT_STAMP(var) const unsigned long long var = rt_stamp()
+#define RT_ACC(sum, a, b) sum += (b) - (a)
+#else
+#define RT_STAMP(var)
+#define RT_ACC(sum, a, b)
+#endif
+
+constexpr int kWaveSize = 64;
+constexpr uint32_t kMaxLevels = 6;  // levels of group bounds (4-ary): 128 * 4^5 groups at most
+constexpr uint32_t kQueueBlock = 256;  // paths a wave takes from the global queue per atomic
+
+struct TraceParams {
+    // scene
+    // Spheres are stored CLUSTERED: groups of four spatially close spheres (Morton order; large spheres alone),
+    // each group with a conservative bounding sphere.  Results do not depend on the order: the closest-hit
+    // update breaks ties by the ORIGINAL list index (orig[]).
+    const float4* scan;        // [n_padded] cx, cy, cz, r*r in clustered order (padding: never-hit entries, r*r = -1e30)
+    const uint32_t* orig;      // [n_padded] original list index of each entry (0xffffffff for padding)
+    const float4* leaf;        // [n_padded] conservative one-sphere bounds (cx, cy, cz, |c|^2 - rf^2) for the sphere-level filter
+    // Bounds hierarchy (4-ary): level 0 = the groups, level k+1 node j = level-k nodes 4j..4j+3; the top level
+    // (<= 128 nodes) is filtered on the matrix cores, lower levels are descended per lane.
+    const float4* tree;        // all levels, level 0 first: Cx, Cy, Cz, |C|^2 - Rf^2
+    uint32_t level_off[kMaxLevels], level_cnt[kMaxLevels];
+    uint32_t n_levels;
+    uint32_t tree_in_lds;      // tree mode: stage every level of bounds into LDS (else the descent reads them through L2)
+    const float* radius;       // [n_padded] per scan entry (clustered order)
+    const rt_material* mats;   // [n_padded] per scan entry: material i of the reference belongs to sphere i = orig[entry]
+    uint32_t n;                // real spheres
+    uint32_t n_groups;         // groups of four entries (even)
+    uint32_t mats_in_lds;      // stage the material table into LDS (else it is read through L2)
+    float bound_norm;          // max over groups of |C| + R (scale of the filter's behind-the-origin threshold)
+    uint32_t n_padded;         // 4 * n_groups + 4
+    // Exact shadow index for the (single, directional) sun: spheres binned by their footprint in the plane
+    // perpendicular to the light.  Valid for hit points with |p|^2 <= sg_p0sq.
+    const uint16_t* sg_cell_start;  // [sg_nx * sg_ny + 1]
+    const uint16_t* sg_entries;     // clustered entry indices per cell
+    const uint16_t* sg_global;      // entries tested for every query (footprints covering much of the grid)
+    uint32_t sg_nx, sg_ny, sg_nglobal, sg_nentries, sg_enabled, sg_in_lds;
+    float sg_e1[3], sg_e2[3], sg_u0, sg_v0, sg_inv_cell, sg_p0sq;
+    float cam_o[3], cam_x[3], cam_y[3], cam_oip[3];
+    float aperture, focal;
+    float sun_dir[3], sun_rad[3];  // sun_rad = luminance * colour (light.cpp:27, left factor)
+    float sky_emit[3];             // luminance * colour (material.cpp:172-175)
+    float exposure;
+    // work
+    uint32_t W, H;
+    rt_rowset rs;
+    uint32_t s0;          // first sample index of this pass (1-based)
+    uint32_t spp_pass;    // samples per pixel in this pass
+    uint32_t total_paths; // W * local_rows * spp_pass, or the path-list length
+    uint32_t npix_local;  // W * local_rows (the sample buffer is [sample of the pass][local pixel])
+    uint32_t max_depth;
+    uint64_t seed;
+    const uint32_t* path_list;  // optional explicit (i, j, s) triples (unit tests)
+    const float2* jitter_tab;   // [spp_pass] Halton2D(s;2,3) for s = s0.. (rt_raygen_tables_kernel), or null
+    const float2* lens_tab;     // [.] HaltonSampleDisk(k;4,5) for k = lens_k0.., or null
+    uint32_t lens_k0;
+    float* samples;             // [total_paths][3] radiance * exposure
+    uint32_t* trav_out;         // optional per-path traversal counts
+    uint32_t ray_cache_off16;  // float4 offset of the per-wave prepared-path caches in dynamic LDS, 0 = no cache
+    uint32_t* queue_head;       // global work counter, zeroed before launch
+    unsigned long long* counters;  // [0] traversals, [1] segments
+};
+
+// The scene and pass constants the hit processing and the ray generation read, copied once per workgroup into LDS
+// (rt_trace_kernel): as kernel arguments they live in SGPRs for the whole persistent loop (~60 of them, spilled to VGPR
+// lanes and read back with v_readlane at every use, and an SGPR source halves the VOP2 issue rate); from LDS they are
+// short-lived VGPR temporaries.  Member names equal TraceParams' so that the device functions below take either.
+struct SceneConsts {
+    float cam_o[3], cam_x[3], cam_y[3], cam_oip[3];
+    float aperture, focal;
+    float sun_dir[3], sun_rad[3];
+    float sky_emit[3];
+    float exposure;
+    float sg_e1[3], sg_e2[3], sg_u0, sg_v0, sg_inv_cell, sg_p0sq;
+    uint32_t sg_nx, sg_ny, sg_nglobal, sg_enabled;
+    uint32_t W, H, s0, lens_k0;
+    const float2* jitter_tab;
+    const float2* lens_tab;
+};
+constexpr uint32_t kConstBytes = 256;  // LDS reserved for SceneConsts at the start of the dynamic image
+static_assert(sizeof(SceneConsts) <= kConstBytes, "SceneConsts must fit its LDS slot");
+RT_DEV void fill_consts(const TraceParams& p, SceneConsts& k) {
+    for (int i = 0; i < 3; ++i) {
+        k.cam_o[i] = p.cam_o[i]; k.cam_x[i] = p.cam_x[i]; k.cam_y[i] = p.cam_y[i]; k.cam_oip[i] = p.cam_oip[i];
+        k.sun_dir[i] = p.sun_dir[i]; k.sun_rad[i] = p.sun_rad[i]; k.sky_emit[i] = p.sky_emit[i];
+        k.sg_e1[i] = p.sg_e1[i]; k.sg_e2[i] = p.sg_e2[i];
+    }
+    k.aperture = p.aperture; k.focal = p.focal; k.exposure = p.exposure;
+    k.sg_u0 = p.sg_u0; k.sg_v0 = p.sg_v0; k.sg_inv_cell = p.sg_inv_cell; k.sg_p0sq = p.sg_p0sq;
+    k.sg_nx = p.sg_nx; k.sg_ny = p.sg_ny; k.sg_nglobal = p.sg_nglobal; k.sg_enabled = p.sg_enabled;
+    k.W = p.W; k.H = p.H; k.s0 = p.s0; k.lens_k0 = p.lens_k0;
+    k.jitter_tab = p.jitter_tab; k.lens_tab = p.lens_tab;
+}
+
+// --------------------------------------------------------------------------- row sets
+RT_DEV uint32_t rowset_global_row(const rt_rowset& rs, uint32_t lr) {
+    const uint32_t lb = lr / rs.block_rows;
+    const uint32_t k = lr - lb * rs.block_rows;
+    return rs.first_row + (lb * rs.nshards + rs.shard) * rs.block_rows + k;
+}
+
+// Camera::GetRay (camera.cpp:30-48)
+template <class P>
+RT_DEV void camera_get_ray(const P& p, float uvx, float uvy, float lensx, float lensy, V3& origin, V3& dir) {
+    const V3 camO = v3(p.cam_o[0], p.cam_o[1], p.cam_o[2]);
+    const V3 mx = v3(p.cam_x[0], p.cam_x[1], p.cam_x[2]);
+    const V3 my = v3(p.cam_y[0], p.cam_y[1], p.cam_y[2]);
+    const V3 oip = v3(p.cam_oip[0], p.cam_oip[1], p.cam_oip[2]);
+    const float ndcx = 2.f * uvx - 1.f;
+    const float ndcy = -2.f * uvy + 1.f;
+    const V3 pp = (oip + ndcx * mx) + ndcy * my;
+    const V3 focalPoint = camO + p.focal * normalize3(pp - camO);
+    const float rdx = (0.5f * p.aperture) * lensx;
+    const float rdy = (0.5f * p.aperture) * lensy;
+    origin = (camO + rdx * mx) + rdy * my;
+    dir = normalize3(focalPoint - origin);
+}
+
+// ------------------------------------------------------------------ primary rays (A1, A2)
+// SpheresApp::GenerateRays (spheres-app.cpp:132-161) + Camera::GetRay (camera.cpp:30-48) for one
+// (i, j, s).  jitter = Halton2D(s;2,3); lens = HaltonSampleDisk(s+i+j;4,5).
+RT_DEV void halton_disk_4_5(uint32_t k, float& lensx, float& lensy) {  // quasi-random.cpp:52-61
+    const float theta = (2.f * 3.141592654f) * halton(k, 4);
+    const float r = halton(k, 5);
+    double sn, cs;
+    sincos_f64(theta, sn, cs);
+    lensx = r * (float)cs;
+    lensy = r * (float)sn;
+}
+template <class P>
+RT_DEV void gen_primary_ray(const P& p, uint32_t i, uint32_t j, uint32_t s, V3& origin, V3& dir) {
+    const float xsize = (float)p.W;
+    const float ysize = (float)p.H;
+    float jx, jy, lensx, lensy;
+    const uint32_t li = s + i + j;
+    if (p.jitter_tab) {
+        // the radical inverses depend on s (jitter) and s+i+j (lens) only: a per-pass device kernel
+        // tabulates them so that a refilled lane does two 8-byte loads instead of four divide loops
+        const float2 jt = p.jitter_tab[s - p.s0];
+        const float2 lt = p.lens_tab[li - p.lens_k0];
+        jx = jt.x; jy = jt.y; lensx = lt.x; lensy = lt.y;
+    } else {
+        jx = halton(s, 2);
+        jy = halton(s, 3);
+        halton_disk_4_5(li, lensx, lensy);
+    }
+    const float uvx = ((float)(int)i + jx) / xsize;
+    const float uvy = ((float)(int)j + jy) / ysize;
+
+    camera_get_ray(p, uvx, uvy, lensx, lensy, origin, dir);
+}
+
+
+}  // namespace rtd

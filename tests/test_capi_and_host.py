@@ -126,7 +126,7 @@ def test_clustered_layout_is_a_partition_with_enclosing_bounds(built, oracle, na
     assert sorted(members.tolist()) == list(range(sc.n))
     c = np.stack([sc.spheres["cx"], sc.spheres["cy"], sc.spheres["cz"]], 1).astype(np.float64)
     r = sc.spheres["r"].astype(np.float64)
-    # rt_kernels.h: kMarginK = 4096 when the groups ARE the matrix-core level (<= 128 groups), kMarginKValu = 2048
+    # rt_scan.h: kMarginK = 4096 when the groups ARE the matrix-core level (<= 128 groups), kMarginKValu = 2048
     # when a hierarchy sits above them and they are tested on the VALU
     keps = (4096 if orig.shape[0] <= 128 else 2048) * 2.0 ** -24
     for g in range(orig.shape[0]):

@@ -1,7 +1,7 @@
 """CPU emulation of the matrix-core filter's arithmetic (split-bf16 operands, f32 accumulation, the margins the host
 folds into the bounds) against the reference-order f32 discriminant: the filter must never reject a (ray, group) pair
 for which a member sphere has a positive reference discriminant.  No GPU: the bounds come from rt_unit_layout (host
-code of librt_hip.so), the arithmetic is re-stated here in numpy (rt_kernels.h scan_list_mfma)."""
+code of librt_hip.so), the arithmetic is re-stated here in numpy (rt_scan.h scan_list_mfma)."""
 import ctypes as C
 
 import numpy as np
