@@ -645,6 +645,7 @@ void rt_destroy(rt_ctx* ctx) {
     ctx->counters.Release();
     ctx->jitterTab.Release();
     ctx->lensTab.Release();
+    ctx->leaf.Release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);

@@ -49,9 +49,15 @@ class HipRenderer:
         check(self._L.rt_scene_upload(self._h, sph.ctypes.data, mat.ctypes.data, sph.shape[0], C.byref(cam), C.byref(sun),
                                       C.byref(sky), float(scene.exposure_scale)))
 
-    def render(self, W, H, s0, s1, max_depth, seed, rowset=None):
+    def render(self, W, H, s0, s1, max_depth, seed, rowset=None, stats=True):
+        """rt_render; stats=False passes out_stats = NULL: the call only enqueues work (progressive frames are then
+        replayed from a captured hipGraph) and returns None."""
         rs = rowset if rowset is not None else whole_image(H)
         rs = RtRowset.from_buffer_copy(bytes(rs))
+        if not stats:
+            check(self._L.rt_render(self._h, W, H, rs, s0, s1, max_depth, seed, None))
+            self.W, self.rows = W, self._L.rt_rowset_local_rows(rs)
+            return None
         st = RtStats()
         check(self._L.rt_render(self._h, W, H, rs, s0, s1, max_depth, seed, C.byref(st)))
         self.W, self.rows = W, st.local_rows
