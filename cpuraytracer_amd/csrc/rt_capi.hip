@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <unordered_map>
 #include <array>
 #include <vector>
 
@@ -67,6 +69,7 @@ struct rt_ctx {
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> passEv;  // three timing events per sample-range pass of rt_render, grown on demand
     int cuCount = 0;
     size_t ldsPerBlockMax = 0;
     uint64_t workspaceLimit = 8ull << 30;
@@ -103,6 +106,7 @@ struct rt_ctx {
     bool treeInLds = true;      // RT_TREE_LDS=0: the hierarchy's bounds are read through L2
     uint32_t treeTop = 128;  // largest top level the matrix-core filter takes (4 tiles of 32); RT_TREE_TOP overrides
     bool forceGlobal = false;
+    std::unordered_map<const void*, size_t> ldsAttr;  // dynamic-LDS limit last set per kernel variant (LaunchTrace)
 };
 
 static uint32_t RowsetLocalRows(rt_rowset rs) {
@@ -498,12 +502,33 @@ static size_t LdsBytesFor(uint32_t n, uint32_t nPadded, bool mats) {
 }
 static size_t MfmaOpsBytesFor(uint32_t nGroups) { return (size_t)rtd::mfma_tiles_for(nGroups) * rtd::kOpsPerTile * 4; }
 
+// Which instantiation of rt_trace_kernel a scene gets under this context's settings (also used by the closest-hit unit
+// entry, so that it runs the scan rt_render runs): tree = hierarchy scan <false, ., 2>, flat = matrix-core filter over the
+// groups with every table in LDS <true, ., 1>, else the VALU scan with (ldsTables) or without LDS tables.
+struct TraceVariant {
+    bool tree, flat, ldsTables;
+    size_t candBytes, leafBytes;
+};
+static TraceVariant ChooseVariant(const rt_ctx* ctx, const rtd::TraceParams& tp) {
+    TraceVariant V{};
+    const size_t lds = LdsBytesFor(tp.n, tp.n_padded, ctx->matsInLds);
+    const bool useLds = !ctx->forceGlobal && lds <= 48 * 1024 && tp.n_padded < 65536;
+    const uint32_t wavesPerBlock = ctx->blockThreads / 64;
+    V.tree = ctx->useMfma && tp.n_levels > 1;  // deeper hierarchy: tables stay in global memory (L2)
+    const uint32_t topCnt = tp.level_cnt[tp.n_levels - 1];
+    // the scene constants' slot comes first in the image, then the per-wave regions
+    V.candBytes = rtd::kConstBytes + (size_t)wavesPerBlock * (V.tree ? rtd::kWaveCandBytes : rtd::kWaveListBytes);
+    V.leafBytes = (size_t)tp.n_padded * 16;  // one-sphere bounds, staged next to the scan table by the flat scan
+    V.flat = !V.tree && useLds && ctx->useMfma && (V.candBytes + lds + V.leafBytes + MfmaOpsBytesFor(topCnt)) <= 160 * 1024;
+    V.ldsTables = useLds && !V.tree;
+    return V;
+}
+
 // Launch the megakernel over total paths described by tp.
 static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     RT_HIP(hipMemsetAsync(ctx->queue.ptr, 0, sizeof(uint32_t), ctx->stream));
     tp.mats_in_lds = ctx->matsInLds ? 1u : 0u;
     const size_t lds = LdsBytesFor(tp.n, tp.n_padded, ctx->matsInLds);
-    const bool useLds = !ctx->forceGlobal && lds <= 48 * 1024 && tp.n_padded < 65536;
     if (tp.n_padded >= 65536) return Fail(RT_ERR_INVALID_ARG, "scenes beyond 65,000 spheres are not supported by the 16-bit candidate lists");
     const uint32_t maxBlocks = (uint32_t)ctx->cuCount * ctx->blocksPerCu;
     // one wave holds 64 paths; do not launch more waves than there is work for
@@ -513,13 +538,10 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks == 0) blocks = 1;
     // dynamic LDS: per-wave candidate regions + the scene tables when they fit + the filter operand image
-    const bool tree = ctx->useMfma && tp.n_levels > 1;  // deeper hierarchy: tables stay in global memory (L2)
+    const TraceVariant V = ChooseVariant(ctx, tp);
+    const bool tree = V.tree, flat = V.flat, ldsTables = V.ldsTables;
     const uint32_t topCnt = tp.level_cnt[tp.n_levels - 1];
-    // the scene constants' slot comes first in the image, then the per-wave regions
-    const size_t candBytes = rtd::kConstBytes + (size_t)wavesPerBlock * (tree ? rtd::kWaveCandBytes : rtd::kWaveListBytes);
-    const size_t leafBytes = (size_t)tp.n_padded * 16;  // one-sphere bounds, staged next to the scan table by the flat scan
-    const bool flat = !tree && useLds && ctx->useMfma && (candBytes + lds + leafBytes + MfmaOpsBytesFor(topCnt)) <= 160 * 1024;
-    const bool ldsTables = useLds && !tree;
+    const size_t candBytes = V.candBytes, leafBytes = V.leafBytes;
     size_t sgBytes = (flat && tp.sg_enabled) ? (((size_t)tp.sg_nx * tp.sg_ny + 1 + tp.sg_nentries + tp.sg_nglobal) * 2 + 15) / 16 * 16 : 0;
     if (candBytes + lds + leafBytes + MfmaOpsBytesFor(topCnt) + sgBytes > 160 * 1024) sgBytes = 0;  // index stays in global memory (L2)
     tp.sg_in_lds = sgBytes ? 1u : 0u;
@@ -536,9 +558,12 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     }
 #define RT_LAUNCH_C(LDS, T, M, C)                                                                                                  \
     do {                                                                                                                      \
-        if (ldsBytes > 48 * 1024)                                                                                             \
-            RT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rtd::rt_trace_kernel<LDS, T, M, C>),                     \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));                           \
+        const void* fn_ = reinterpret_cast<const void*>(&rtd::rt_trace_kernel<LDS, T, M, C>);                                  \
+        size_t& set_ = ctx->ldsAttr[fn_];  /* the attribute call costs host time on launch-bound 1-spp frames: only on change */ \
+        if (ldsBytes > 48 * 1024 && set_ != ldsBytes) {                                                                       \
+            RT_HIP(hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));                      \
+            set_ = ldsBytes;                                                                                                  \
+        }                                                                                                                     \
         hipLaunchKernelGGL((rtd::rt_trace_kernel<LDS, T, M, C>), dim3(blocks), dim3(T), ldsBytes, ctx->stream, tp);           \
     } while (0)
 #define RT_LAUNCH(LDS, T, M)                        \
@@ -589,7 +614,10 @@ int rt_create(int device_ordinal, rt_ctx** out) {
                                           "); this library has no CPU fallback");
     if (device_ordinal < 0 || device_ordinal >= count) return Fail(RT_ERR_NO_DEVICE, "rt_create: device ordinal out of range");
     RT_HIP(hipSetDevice(device_ordinal));
-    rt_ctx* ctx = new rt_ctx();
+    // owned until the end: every early return below releases what has been created so far (rt_destroy copes with
+    // half-initialised contexts)
+    std::unique_ptr<rt_ctx, void (*)(rt_ctx*)> guard(new rt_ctx(), rt_destroy);
+    rt_ctx* ctx = guard.get();
     ctx->device = device_ordinal;
     hipDeviceProp_t prop;
     RT_HIP(hipGetDeviceProperties(&prop, device_ordinal));
@@ -617,12 +645,20 @@ int rt_create(int device_ordinal, rt_ctx** out) {
     if (ctx->blockThreads != 256 && ctx->blockThreads != 512 && ctx->blockThreads != 1024) ctx->blockThreads = 256;
     int rc = ctx->queue.Reserve(1);
     if (rc == RT_OK) rc = ctx->counters.Reserve(2);
-    if (rc != RT_OK) {
-        delete ctx;
-        return rc;
+    if (rc != RT_OK) return rc;
+    {
+        // sample-buffer workspace: sized for this GPU's HBM (288 GB on MI355X), so that BASELINE configs 3 (on one GPU:
+        // 11.8 GB) and 5 (12.9 GB) run as ONE pass; RT_WORKSPACE_GIB or rt_set_workspace_limit override
+        size_t freeB = 0, totalB = 0;
+        RT_HIP(hipMemGetInfo(&freeB, &totalB));
+        uint64_t lim = 64ull << 30;
+        if (lim > freeB / 2) lim = freeB / 2;
+        const uint32_t envGiB = EnvU32("RT_WORKSPACE_GIB", 0);
+        if (envGiB) lim = (uint64_t)envGiB << 30;
+        if (lim < (1ull << 20)) lim = 1ull << 20;
+        ctx->workspaceLimit = lim;
     }
-    // the LDS variant may need more than the default 64 KiB dynamic LDS limit in later rounds
-    *out = ctx;
+    *out = guard.release();
     return RT_OK;
 }
 
@@ -648,6 +684,8 @@ void rt_destroy(rt_ctx* ctx) {
     ctx->leaf.Release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : ctx->passEv)
+        if (ev) (void)hipEventDestroy(ev);
     if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
     delete ctx;
 }
@@ -672,6 +710,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     int rc;
     SceneLayout L;
     BuildLayout(spheres, n, ctx->treeTop, L);
+    // work lists, the shadow index and the closest-hit keys carry scan-entry ids in 16 bits
+    if (L.scan.size() >= 65536) return Fail(RT_ERR_INVALID_ARG, "rt_scene_upload: scenes beyond 65,535 scan entries (about 65,000 spheres) are not supported");
     const uint32_t nPad = (uint32_t)L.scan.size();
     if ((rc = ctx->scan.Reserve(nPad)) != RT_OK) return rc;
     if ((rc = ctx->orig.Reserve(nPad)) != RT_OK) return rc;
@@ -813,63 +853,80 @@ int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, ui
     int rc;
     if ((rc = ctx->samples.Reserve((size_t)npix * sppPass * 3)) != RT_OK) return rc;
 
-    RT_HIP(hipMemsetAsync(ctx->counters.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    float msTrace = 0.f, msAcc = 0.f;
+    // Passes run back to back on the stream: trace(k) -> accumulate(k) -> trace(k+1) are ordered by the stream itself
+    // (they share the sample buffer), so the host never waits between passes; each pass has its own three timing
+    // events, read once at the end when the caller asked for statistics.
     uint32_t passes = 0;
-    for (uint32_t s = s0; s < s1; s += sppPass) {
-        const uint32_t spp = (s1 - s) < sppPass ? (s1 - s) : sppPass;
-        rtd::TraceParams tp = ctx->base;
-        tp.W = W;
-        tp.H = H;
-        tp.rs = rs;
-        tp.s0 = s;
-        tp.spp_pass = spp;
-        tp.total_paths = npix * spp;
-        tp.npix_local = npix;
-        tp.max_depth = max_depth;
-        tp.seed = seed;
-        tp.path_list = nullptr;
-        tp.samples = ctx->samples.ptr;
-        tp.trav_out = nullptr;
-        tp.queue_head = ctx->queue.ptr;
-        tp.counters = ctx->counters.ptr;
-        // ray-generation tables for this pass: s in [s, s+spp), k = s+i+j over the strip's rows
-        const uint32_t k0 = s + rs.first_row;
-        const uint32_t nLens = spp + W + rs.num_rows;
-        if ((rc = ctx->jitterTab.Reserve(spp)) != RT_OK) return rc;
-        if ((rc = ctx->lensTab.Reserve(nLens)) != RT_OK) return rc;
-        tp.jitter_tab = ctx->jitterTab.ptr;
-        tp.lens_tab = ctx->lensTab.ptr;
-        tp.lens_k0 = k0;
-        RT_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-        {
-            const uint32_t nmax = spp > nLens ? spp : nLens;
-            hipLaunchKernelGGL(rtd::rt_raygen_tables_kernel, dim3((nmax + 255) / 256), dim3(256), 0, ctx->stream, ctx->jitterTab.ptr, s, spp,
-                               ctx->lensTab.ptr, k0, nLens);
+    auto runPasses = [&]() -> int {
+        int rc;
+        RT_HIP(hipMemsetAsync(ctx->counters.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        for (uint32_t s = s0; s < s1; s += sppPass) {
+            const uint32_t spp = (s1 - s) < sppPass ? (s1 - s) : sppPass;
+            rtd::TraceParams tp = ctx->base;
+            tp.W = W;
+            tp.H = H;
+            tp.rs = rs;
+            tp.s0 = s;
+            tp.spp_pass = spp;
+            tp.total_paths = npix * spp;
+            tp.npix_local = npix;
+            tp.max_depth = max_depth;
+            tp.seed = seed;
+            tp.path_list = nullptr;
+            tp.samples = ctx->samples.ptr;
+            tp.trav_out = nullptr;
+            tp.queue_head = ctx->queue.ptr;
+            tp.counters = ctx->counters.ptr;
+            // ray-generation tables for this pass: s in [s, s+spp), k = s+i+j over the strip's rows
+            const uint32_t k0 = s + rs.first_row;
+            const uint32_t nLens = spp + W + rs.num_rows;
+            if ((rc = ctx->jitterTab.Reserve(spp)) != RT_OK) return rc;
+            if ((rc = ctx->lensTab.Reserve(nLens)) != RT_OK) return rc;
+            tp.jitter_tab = ctx->jitterTab.ptr;
+            tp.lens_tab = ctx->lensTab.ptr;
+            tp.lens_k0 = k0;
+            while (ctx->passEv.size() < 3 * (size_t)(passes + 1)) {
+                hipEvent_t e = nullptr;
+                RT_HIP(hipEventCreate(&e));
+                ctx->passEv.push_back(e);
+            }
+            hipEvent_t* ev = ctx->passEv.data() + 3 * (size_t)passes;
+            RT_HIP(hipEventRecord(ev[0], ctx->stream));
+            {
+                const uint32_t nmax = spp > nLens ? spp : nLens;
+                hipLaunchKernelGGL(rtd::rt_raygen_tables_kernel, dim3((nmax + 255) / 256), dim3(256), 0, ctx->stream, ctx->jitterTab.ptr, s,
+                                   spp, ctx->lensTab.ptr, k0, nLens);
+                RT_HIP(hipGetLastError());
+            }
+            if ((rc = LaunchTrace(ctx, tp)) != RT_OK) return rc;
+            RT_HIP(hipEventRecord(ev[1], ctx->stream));
+            hipLaunchKernelGGL(rtd::rt_accumulate_kernel, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, ctx->samples.ptr,
+                               ctx->hdr.ptr, npix, spp);
             RT_HIP(hipGetLastError());
+            RT_HIP(hipEventRecord(ev[2], ctx->stream));
+            ++passes;
         }
-        if ((rc = LaunchTrace(ctx, tp)) != RT_OK) return rc;
-        RT_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-        hipLaunchKernelGGL(rtd::rt_accumulate_kernel, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, ctx->samples.ptr, ctx->hdr.ptr,
-                           npix, spp);
-        RT_HIP(hipGetLastError());
-        RT_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-        ++passes;
-        // Without a stats request the call stays asynchronous on the stream (progressive 1-spp frames are launch
-        // bound: ~0.2 ms of GPU work each); with one it waits for the pass to read the event timers.  A multi-pass
-        // render must wait anyway before the next pass reuses the workspace's event objects.
-        if (out_stats || s + sppPass < s1) {
-            RT_HIP(hipEventSynchronize(ctx->ev[2]));
-            float a = 0.f, b = 0.f;
-            RT_HIP(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
-            RT_HIP(hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
-            msTrace += a;
-            msAcc += b;
-        }
+        return RT_OK;
+    };
+    if ((rc = runPasses()) != RT_OK) {
+        // some passes may already have been added to hdr: the accumulation is void, the next call must restart at s0 == 1
+        ctx->accumulated = 0;
+        return rc;
     }
     ctx->accumulated += sppTotal;
 
     if (out_stats) {
+        // Without a stats request the call stays asynchronous on the stream (progressive 1-spp frames are launch bound:
+        // ~0.2 ms of GPU work each); with one it waits for the last pass and reads the event timers.
+        float msTrace = 0.f, msAcc = 0.f;
+        RT_HIP(hipEventSynchronize(ctx->passEv[3 * (size_t)(passes - 1) + 2]));
+        for (uint32_t k = 0; k < passes; ++k) {
+            float a = 0.f, b = 0.f;
+            RT_HIP(hipEventElapsedTime(&a, ctx->passEv[3 * (size_t)k], ctx->passEv[3 * (size_t)k + 1]));
+            RT_HIP(hipEventElapsedTime(&b, ctx->passEv[3 * (size_t)k + 1], ctx->passEv[3 * (size_t)k + 2]));
+            msTrace += a;
+            msAcc += b;
+        }
         unsigned long long c[2] = {0, 0};
         RT_HIP(hipMemcpy(c, ctx->counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
         std::memset(out_stats, 0, sizeof(*out_stats));
@@ -996,7 +1053,36 @@ int rt_unit_closest_hit(rt_ctx* ctx, const float* rays, uint32_t n, float* out_h
     RT_HIP(dRays.Alloc((size_t)n * 6));
     RT_HIP(dOut.Alloc((size_t)n * 10));
     RT_HIP(hipMemcpy(dRays.p, rays, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(rtd::k_unit_closest, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->base, dRays.p, n, dOut.p);
+    {
+        // the scan variant rt_render would launch for this scene; LDS image for four waves, hit-processing tables left out
+        rtd::TraceParams tp = ctx->base;
+        const TraceVariant V = ChooseVariant(ctx, tp);
+        tp.mats_in_lds = 0;
+        tp.sg_in_lds = 0;
+        const uint32_t topCnt = tp.level_cnt[tp.n_levels - 1];
+        const size_t waves = 256 / 64;
+        size_t ldsBytes = waves * (V.tree ? rtd::kWaveCandBytes : rtd::kWaveListBytes);
+        if (V.tree) {
+            ldsBytes += MfmaOpsBytesFor(topCnt);
+            const size_t treeBytes = (size_t)(tp.level_off[tp.n_levels - 1] + topCnt) * 16;
+            tp.tree_in_lds = (ctx->treeInLds && ldsBytes + treeBytes <= 160 * 1024) ? 1u : 0u;
+            if (tp.tree_in_lds) ldsBytes += treeBytes;
+        } else if (V.flat || V.ldsTables) {
+            ldsBytes += LdsBytesFor(tp.n, tp.n_padded, false);
+            if (V.flat) ldsBytes += V.leafBytes + MfmaOpsBytesFor(topCnt);
+        }
+#define RT_UNIT_CLOSEST(LDS, M)                                                                                        \
+    do {                                                                                                               \
+        const void* fn_ = reinterpret_cast<const void*>(&rtd::k_unit_closest<LDS, M>);                                 \
+        if (ldsBytes > 48 * 1024) RT_HIP(hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
+        hipLaunchKernelGGL((rtd::k_unit_closest<LDS, M>), dim3((n + 255) / 256), dim3(256), ldsBytes, ctx->stream, tp, dRays.p, n, dOut.p); \
+    } while (0)
+        if (V.tree) RT_UNIT_CLOSEST(false, 2);
+        else if (V.flat) RT_UNIT_CLOSEST(true, 1);
+        else if (V.ldsTables) RT_UNIT_CLOSEST(true, 0);
+        else RT_UNIT_CLOSEST(false, 0);
+#undef RT_UNIT_CLOSEST
+    }
     RT_HIP(hipGetLastError());
     RT_HIP(hipStreamSynchronize(ctx->stream));
     RT_HIP(hipMemcpy(out_hits, dOut.p, (size_t)n * 10 * sizeof(float), hipMemcpyDeviceToHost));

@@ -77,41 +77,42 @@ RT_DEV void path_coordinates(const TraceParams& p, uint32_t q, uint32_t& i, uint
     }
 }
 
-// ============================================================================ megakernel
-// Persistent threads: every wave loops { refill idle lanes from the queue; one list scan for all
-// lanes; per-lane state transition } until the queue is empty and all its lanes are idle.  Waves
-// never synchronise with each other after the LDS staging barrier, and every wave's loop ends when
-// the (bounded, monotonically consumed) queue is exhausted and its at most 64 paths of at most
-// max_depth+1 segments have finished.
-// kScan: 0 = VALU sign filter per group (any scene size), 1 = matrix-core filter over the groups (tables in LDS),
-// 2 = matrix-core filter over the top level of the bounds hierarchy + per-lane descent (tables through L2).
-template <bool kLds, int kThreads, int kScan, bool kCache>
-__global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams p) {
+// Scene tables as the scan and the hit processing read them: LDS copies when the launch staged them, else global (L2).
+struct SceneTabs {
+    const float4* scan;
+    const uint32_t* orig;
+    const float4* leaf;
+    const float* rad;
+    const rt_material* mats;
+    const float* ops;       // filter operand image of the top level (matrix-core scans)
+    const float4* tree;
+    const uint16_t *sgCell, *sgEntries, *sgGlobal;
+    uint32_t nTop, nTiles;
+};
+
+// Workgroup prologue shared by the megakernel and the closest-hit unit kernel: copy the scene tables the variant keeps in
+// LDS to tabBase (16-byte aligned pieces: scan | one-sphere bounds (flat matrix-core scan only) | orig | materials (48 B =
+// 3 float4) | radii | filter operands | shadow index; tree mode: operands | all levels of bounds) and build the filter's
+// operand image.  Every thread of the workgroup must call it.
+template <bool kLds, int kScan>
+RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
     constexpr bool kMfma = kScan != 0;
-    extern __shared__ float4 smem[];
-    const float4* scanTab = p.scan;
-    const uint32_t* origTab = p.orig;
-    const float4* leafTab = p.leaf;
-    const float* radTab = p.radius;
-    const rt_material* matTab = p.mats;
-    // per-wave candidate regions first (kWaveCandBytes each; the VALU scan uses the first 2 KiB of its region)
-    // [0, kConstBytes): the scene constants; then the per-wave regions; then the tables
-    SceneConsts* ldsK = reinterpret_cast<SceneConsts*>(smem);
-    if (threadIdx.x == 0) fill_consts(p, *ldsK);
-    uint16_t* candBase = reinterpret_cast<uint16_t*>(smem + kConstBytes / 16);
-    constexpr uint32_t kWaveRegion = kScan == 2 ? kWaveCandBytes : kWaveListBytes;  // the descent stack only exists in tree mode
-    float4* tabBase = smem + kConstBytes / 16 + (kThreads / kWaveSize) * (kWaveRegion / 16);
-    const float* mfmaOps = nullptr;
-    const float4* treeTab = p.tree;
-    const uint16_t* sgCell = p.sg_cell_start;
-    const uint16_t* sgEntries = p.sg_entries;
-    const uint16_t* sgGlobal = p.sg_global;
+    T.scan = p.scan;
+    T.orig = p.orig;
+    T.leaf = p.leaf;
+    T.rad = p.radius;
+    T.mats = p.mats;
+    T.ops = nullptr;
+    T.tree = p.tree;
+    T.sgCell = p.sg_cell_start;
+    T.sgEntries = p.sg_entries;
+    T.sgGlobal = p.sg_global;
     const uint32_t topLevel = p.n_levels - 1u;
     const uint32_t nTop = p.level_cnt[topLevel];
     const uint32_t nTiles = mfma_tiles_for(nTop);  // even; nTop <= 128 => at most four
+    T.nTop = nTop;
+    T.nTiles = nTiles;
     if (kLds) {
-        // LDS image (16-byte aligned pieces): scan | one-sphere bounds (matrix-core scan only) | orig | materials (48 B =
-        // 3 float4) | radii | filter operands | shadow index
         float4* ldsScan = tabBase;
         float4* ldsLeaf = ldsScan + p.n_padded;
         uint32_t* ldsOrig = reinterpret_cast<uint32_t*>(ldsLeaf + (kScan == 1 ? p.n_padded : 0u));
@@ -129,37 +130,70 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         if (kMfma) {
             float* ldsOps = ldsRad + p.n_padded;  // a multiple of 4
             build_mfma_operands(p.tree + p.level_off[topLevel], nTop, nTiles, ldsOps, threadIdx.x, blockDim.x);
-            mfmaOps = ldsOps;
+            T.ops = ldsOps;
             if (p.sg_enabled && p.sg_in_lds) {  // shadow index after the operand image
                 uint16_t* g = reinterpret_cast<uint16_t*>(ldsOps + (size_t)nTiles * kOpsPerTile);
                 const uint32_t nc = p.sg_nx * p.sg_ny + 1u;
                 for (uint32_t k = threadIdx.x; k < nc; k += blockDim.x) g[k] = p.sg_cell_start[k];
                 for (uint32_t k = threadIdx.x; k < p.sg_nentries; k += blockDim.x) g[nc + k] = p.sg_entries[k];
                 for (uint32_t k = threadIdx.x; k < p.sg_nglobal; k += blockDim.x) g[nc + p.sg_nentries + k] = p.sg_global[k];
-                sgCell = g;
-                sgEntries = g + nc;
-                sgGlobal = g + nc + p.sg_nentries;
+                T.sgCell = g;
+                T.sgEntries = g + nc;
+                T.sgGlobal = g + nc + p.sg_nentries;
             }
         }
         __syncthreads();
-        scanTab = ldsScan;
-        origTab = ldsOrig;
-        if (kScan == 1) leafTab = ldsLeaf;
-        radTab = ldsRad;
-        if (p.mats_in_lds) matTab = reinterpret_cast<const rt_material*>(ldsMat);
+        T.scan = ldsScan;
+        T.orig = ldsOrig;
+        if (kScan == 1) T.leaf = ldsLeaf;
+        T.rad = ldsRad;
+        if (p.mats_in_lds) T.mats = reinterpret_cast<const rt_material*>(ldsMat);
     } else if (kMfma) {
         // exact tables stay in global memory (L2); the top level's operand image and, when they fit, all bounds live in LDS
         float* ldsOps = reinterpret_cast<float*>(tabBase);
         build_mfma_operands(p.tree + p.level_off[topLevel], nTop, nTiles, ldsOps, threadIdx.x, blockDim.x);
-        mfmaOps = ldsOps;
+        T.ops = ldsOps;
         if (p.tree_in_lds) {
             float4* ldsTree = reinterpret_cast<float4*>(ldsOps + (size_t)nTiles * kOpsPerTile);
             const uint32_t nNodes = p.level_off[topLevel] + nTop;
             for (uint32_t k = threadIdx.x; k < nNodes; k += blockDim.x) ldsTree[k] = p.tree[k];
-            treeTab = ldsTree;
+            T.tree = ldsTree;
         }
         __syncthreads();
     }
+}
+
+// ============================================================================ megakernel
+// Persistent threads: every wave loops { refill idle lanes from the queue; one list scan for all
+// lanes; per-lane state transition } until the queue is empty and all its lanes are idle.  Waves
+// never synchronise with each other after the LDS staging barrier, and every wave's loop ends when
+// the (bounded, monotonically consumed) queue is exhausted and its at most 64 paths of at most
+// max_depth+1 segments have finished.
+// kScan: 0 = VALU sign filter per group (any scene size), 1 = matrix-core filter over the groups (tables in LDS),
+// 2 = matrix-core filter over the top level of the bounds hierarchy + per-lane descent (tables through L2).
+template <bool kLds, int kThreads, int kScan, bool kCache>
+__global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams p) {
+    constexpr bool kMfma = kScan != 0;
+    extern __shared__ float4 smem[];
+    // [0, kConstBytes): the scene constants; then the per-wave regions; then the tables
+    SceneConsts* ldsK = reinterpret_cast<SceneConsts*>(smem);
+    if (threadIdx.x == 0) fill_consts(p, *ldsK);
+    uint16_t* candBase = reinterpret_cast<uint16_t*>(smem + kConstBytes / 16);
+    constexpr uint32_t kWaveRegion = kScan == 2 ? kWaveCandBytes : kWaveListBytes;  // the descent stack only exists in tree mode
+    float4* tabBase = smem + kConstBytes / 16 + (kThreads / kWaveSize) * (kWaveRegion / 16);
+    SceneTabs T;
+    stage_scene<kLds, kScan>(p, tabBase, T);  // ends with a workgroup barrier when it staged anything
+    const float4* scanTab = T.scan;
+    const uint32_t* origTab = T.orig;
+    const float4* leafTab = T.leaf;
+    const float* radTab = T.rad;
+    const rt_material* matTab = T.mats;
+    const float* mfmaOps = T.ops;
+    const float4* treeTab = T.tree;
+    const uint16_t* sgCell = T.sgCell;
+    const uint16_t* sgEntries = T.sgEntries;
+    const uint16_t* sgGlobal = T.sgGlobal;
+    const uint32_t nTop = T.nTop, nTiles = T.nTiles;
 
     const uint32_t lane = threadIdx.x & (kWaveSize - 1);
     uint16_t* waveCand = candBase + (threadIdx.x / kWaveSize) * (kWaveRegion / 2);
@@ -213,6 +247,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                         }
                     }
                     const uint32_t nGen = (blkEnd - blkNext) < (uint32_t)kWaveSize ? (blkEnd - blkNext) : (uint32_t)kWaveSize;
+                    wave_lds_handoff();  // every slot of the previous batch has been popped
                     if (lane < nGen) {
                         const uint32_t qn = blkNext + lane;
                         uint32_t i, j, s, slotn;
@@ -228,6 +263,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                     blkNext += nGen;
                     cacheCnt = nGen;
                     cachePos = 0;
+                    wave_lds_handoff();  // slots are popped by other lanes than the ones that filled them
                 }
                 const uint32_t avail = cacheCnt - cachePos;
                 const uint32_t want = (uint32_t)__popcll(idleMask);
@@ -524,22 +560,47 @@ __global__ void k_unit_primary(const TraceParams p, const uint32_t* ijs, uint32_
     float* w = out + 6 * (size_t)k;
     w[0] = o.x; w[1] = o.y; w[2] = o.z; w[3] = d.x; w[4] = d.y; w[5] = d.z;
 }
-__global__ void k_unit_closest(const TraceParams p, const float* rays, uint32_t n, float* out) {
+// Closest hit through the PRODUCTION scan of the uploaded scene: the same table staging (stage_scene) and the same
+// scan function (scan_list_mfma flat / hierarchy, or scan_list_deferred) as the variant of rt_trace_kernel that
+// rt_render launches for this scene, 64 rays per wave.  LDS image: per-wave work-list regions, then the tables.
+template <bool kLds, int kScan>
+__global__ void __launch_bounds__(256) k_unit_closest(const TraceParams p, const float* rays, uint32_t n, float* out) {
+    extern __shared__ float4 smem[];
+    constexpr uint32_t kWaveRegion = kScan == 2 ? kWaveCandBytes : kWaveListBytes;
+    uint16_t* candBase = reinterpret_cast<uint16_t*>(smem);
+    float4* tabBase = smem + (256 / kWaveSize) * (kWaveRegion / 16);
+    SceneTabs T;
+    stage_scene<kLds, kScan>(p, tabBase, T);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & (kWaveSize - 1);
+    uint16_t* waveCand = candBase + (threadIdx.x / kWaveSize) * (kWaveRegion / 2);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const float* r = rays + 6 * (size_t)k;
-    const V3 o = v3(r[0], r[1], r[2]), d = v3(r[3], r[4], r[5]);
-    float tmin;
-    int idx;
-    scan_list(p.scan, p.orig, p.n_padded - 4u, o, d, tmin, idx);
+    const bool live = k < n;
+    V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f);
+    if (live) {
+        const float* r = rays + 6 * (size_t)k;
+        o = v3(r[0], r[1], r[2]);
+        d = v3(r[3], r[4], r[5]);
+    }
+    float tmin = 0.f;
+    int idx = -1;
+    unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)dbg;
+    if (kScan != 0) {
+        scan_list_mfma<kScan == 2>(T.scan, T.leaf, T.orig, T.ops, T.nTiles, T.nTop, T.tree, p.level_off, p.n_levels, p.bound_norm, o, d, live,
+                                   tmin, idx, waveCand, lane, dbg);
+    } else if (live) {
+        scan_list_deferred(T.scan, T.orig, p.n_padded, o, d, tmin, idx, waveCand + lane);
+    }
+    if (!live) return;
     float* w = out + 10 * (size_t)k;
     for (int c = 0; c < 10; ++c) w[c] = 0.f;
-    const int oidx = idx >= 0 ? (int)p.orig[idx] : -1;
+    const int oidx = idx >= 0 ? (int)T.orig[idx] : -1;
     w[1] = __int_as_float(oidx);
     if (idx >= 0) {
-        const float4 S = p.scan[idx];
+        const float4 S = T.scan[idx];
         const V3 pos = tmin * d + o;
-        const V3 nrm = (pos - v3(S.x, S.y, S.z)) / p.radius[idx];
+        const V3 nrm = (pos - v3(S.x, S.y, S.z)) / T.rad[idx];
         w[0] = tmin;
         w[2] = pos.x; w[3] = pos.y; w[4] = pos.z;
         w[5] = nrm.x; w[6] = nrm.y; w[7] = nrm.z;

@@ -283,6 +283,16 @@ RT_DEV int bound_rejected(const float4 B, V3 o, V3 d, float a, float dO, float m
     return __float_as_int(f) | (__float_as_int(u) & ~__float_as_int(t));
 }
 
+// Cross-lane hand-off through LDS inside ONE wave (work lists, closest-hit keys, the prepared-path cache): one set of
+// lanes stores, other lanes of the same wave load right after.  The hardware executes a wave's LDS operations in order;
+// this stops the COMPILER from moving may-alias accesses across the hand-off (it emits no instruction beyond, at most, a
+// wait the loads needed anyway).
+RT_DEV void wave_lds_handoff() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // lanes below mine that are set in mask
 RT_DEV uint32_t prefix_count(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -420,12 +430,14 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
         uint16_t* poolB = waveCand + kPoolA;
         unsigned long long* best = reinterpret_cast<unsigned long long*>(waveCand + kPoolA + kPoolB);
         best[lane] = ~0ull;
+        wave_lds_handoff();
         uint32_t cntB = 0;
         const uint32_t nMine = (uint32_t)(__popcll(cur) + __popcll(nxt));
         bool pending = nMine != 0u;
         RT_STAMP(ta0);
         // phase B over the current contents of poolB (wave-uniform count)
         auto drainB = [&]() {
+            wave_lds_handoff();  // poolB entries written by other lanes
             for (uint32_t base = 0; base < cntB; base += kWaveSize) {
                 const uint32_t k = base + lane;
                 const bool has = k < cntB;
@@ -454,6 +466,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                 }
             }
             cntB = 0;
+            wave_lds_handoff();  // poolB may be refilled from here on
         };
         while (__ballot(pending) != 0ull) {
             // lanes whose items fit into the list this pass: a prefix of the pending lanes
@@ -478,6 +491,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                 }
                 pending = false;
             }
+            wave_lds_handoff();  // poolA items written by their owner lanes, read by any lane
             for (uint32_t base = 0; base < total; base += kWaveSize) {
 #ifdef RT_STAMPS
                 dbg[6] += 1;
@@ -504,11 +518,12 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                 }
                 if (cntB > kPoolB - 4u * kWaveSize) drainB();
             }
+            wave_lds_handoff();  // the next pass overwrites poolA
         }
         RT_STAMP(ta1);
         RT_ACC(dbg[4], ta0, ta1);
         drainB();
-        const unsigned long long mineKey = best[lane];
+        const unsigned long long mineKey = best[lane];  // behind drainB's closing hand-off: every lane's minimum is in
         const uint32_t tb = (uint32_t)(mineKey >> 32);
         if (tb < 0x7f800000u) {
             tmin = __uint_as_float(tb);
@@ -528,10 +543,12 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
         uint32_t* exact = work + kTreeWork;                                   // kTreeExact entries: ray << 16 | scan entry
         unsigned long long* best = reinterpret_cast<unsigned long long*>(exact + kTreeExact);
         best[lane] = ~0ull;
+        wave_lds_handoff();
         const uint32_t topLevel = nLevels - 1u;
         const float aoo = a * oo;
         uint32_t nWork = 0, nExact = 0;
         auto drainExact = [&]() {
+            wave_lds_handoff();  // exact-list entries written by other lanes
             for (uint32_t base = 0; base < nExact; base += kWaveSize) {
                 const uint32_t k = base + lane;
                 const bool has = k < nExact;
@@ -556,6 +573,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                 }
             }
             nExact = 0;
+            wave_lds_handoff();  // the exact list may be refilled from here on
         };
         for (;;) {
             // feed: when fewer than a round's worth of pairs is listed, every lane with top-level candidates left adds one
@@ -567,6 +585,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                 nWork += (uint32_t)__popcll(am);
             }
             if (nWork == 0u) break;
+            wave_lds_handoff();  // work-list entries pushed by other lanes (feed above, survivors of the last round)
             const uint32_t room = nWork < kTreeWork - kTreeReserve ? kTreeWork - kTreeReserve - nWork : 0u;
             uint32_t np = room / 3u;
             np = np < 1u ? 1u : np;
@@ -575,6 +594,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
             const bool has = lane < np;
             const uint32_t ent = has ? work[nWork - 1u - lane] : 0u;
             nWork -= np;
+            wave_lds_handoff();  // popped slots are free for this round's pushes
             const uint32_t r = ent >> 20, lvl = (ent >> 16) & 7u, j = ent & 0xffffu;
             const V3 fo = v3(lane_fetch(r, o.x), lane_fetch(r, o.y), lane_fetch(r, o.z));
             const V3 fd = v3(lane_fetch(r, d.x), lane_fetch(r, d.y), lane_fetch(r, d.z));
@@ -613,7 +633,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
             }
         }
         drainExact();
-        const unsigned long long mineKey = best[lane];
+        const unsigned long long mineKey = best[lane];  // behind drainExact's closing hand-off
         const uint32_t tb = (uint32_t)(mineKey >> 32);
         if (tb < 0x7f800000u) {
             tmin = __uint_as_float(tb);

@@ -50,8 +50,8 @@ class HipRenderer:
                                       C.byref(sky), float(scene.exposure_scale)))
 
     def render(self, W, H, s0, s1, max_depth, seed, rowset=None, stats=True):
-        """rt_render; stats=False passes out_stats = NULL: the call only enqueues work (progressive frames are then
-        replayed from a captured hipGraph) and returns None."""
+        """rt_render; stats=False passes out_stats = NULL: the call only enqueues work on the context's stream (no host
+        wait; progressive 1-spp frames are launch bound) and returns None."""
         rs = rowset if rowset is not None else whole_image(H)
         rs = RtRowset.from_buffer_copy(bytes(rs))
         if not stats:

@@ -129,8 +129,10 @@ void rt_destroy(rt_ctx* ctx);
  * the context's own stream. */
 int rt_set_stream(rt_ctx* ctx, void* hip_stream);
 
-/* Upper bound for the per-sample workspace in bytes (default 8 GiB).  A render
- * whose W*rows*(s1-s0)*12 bytes exceed it is split into sample-range passes. */
+/* Upper bound for the per-sample workspace in bytes (default: min(64 GiB, half of the
+ * device's free memory) — sized for 288 GB of HBM, so BASELINE configs 3 and 5 are one
+ * pass on one GPU; env RT_WORKSPACE_GIB overrides).  A render whose W*rows*(s1-s0)*12 bytes
+ * exceed it is split into sample-range passes that run back to back on the stream. */
 int rt_set_workspace_limit(rt_ctx* ctx, uint64_t bytes);
 
 /* ------------------------------------------------------------------ scene */
@@ -138,6 +140,9 @@ int rt_set_workspace_limit(rt_ctx* ctx, uint64_t bytes);
 /* Replaces SpheresApp::InitScene's products (spheres-app.cpp:51-130): n spheres with
  * their materials, the camera (InitCamera, :35-49), the sun, the sky Emissive
  * material and exposureAdjustment = 2^m_exposure (:174). */
+/* Limit: the clustered scan table (groups of four, padded) must stay below 65,536 entries
+ * — about 65,000 spheres — because work lists, the shadow index and the closest-hit keys
+ * carry entry ids in 16 bits; larger scenes are rejected here with RT_ERR_INVALID_ARG. */
 int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* materials, uint32_t n,
                     const rt_camera* camera, const rt_light* sun, const rt_material* sky,
                     float exposure_scale);
@@ -152,7 +157,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
  * the previous s1 continues it (progressive refinement, app.h:26 + spheres-app.h:42).
  * Material random draws come from a per-(pixel,s) xoshiro128** stream seeded from
  * (seed, global pixel id, s) — see DESIGN.md "RNG contract".  With out_stats == NULL the call only enqueues work
- * on the context's stream (no host wait); with out_stats it waits for the kernels to read their timers. */
+ * on the context's stream (no host wait); with out_stats it waits for the kernels to read their timers.
+ * A call that fails part-way voids the accumulation: the next call must start again at s0 == 1. */
 int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1,
               uint32_t max_depth, uint64_t seed, rt_stats* out_stats);
 

@@ -53,13 +53,24 @@ ACCEL_LIST, ACCEL_BVH = 0, 1
 
 
 def build(force=False):
-    """Compile liboracle.so with the committed Makefile (g++, -ffp-contract=off)."""
-    srcs = ["rt_oracle.cpp", "oracle_capi.cpp", "rt_oracle.h", "dxmath_restate.h", "oracle_api.h", "../include/rt_api.h"]
-    if not force and os.path.exists(_LIB_PATH):
-        lib_m = os.path.getmtime(_LIB_PATH)
-        if all(os.path.getmtime(os.path.join(_HERE, s)) <= lib_m for s in srcs):
-            return _LIB_PATH
-    subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    """Compile liboracle.so with the committed Makefile (g++, -ffp-contract=off) when the hash of its sources differs
+    from the one recorded at the last build (content, not mtime: snapshots need not keep modification times)."""
+    import glob
+    import hashlib
+    srcs = sorted(glob.glob(os.path.join(_HERE, "*.cpp")) + glob.glob(os.path.join(_HERE, "*.h")) +
+                  [os.path.join(_HERE, "Makefile"), os.path.join(_HERE, "..", "include", "rt_api.h")])
+    h = hashlib.sha256()
+    for p in srcs:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    want = h.hexdigest()
+    stamp = os.path.join(_HERE, ".build_hash")
+    have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if force or have != want or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-B", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+        with open(stamp, "w") as f:
+            f.write(want + "\n")
     return _LIB_PATH
 
 
