@@ -7,14 +7,27 @@ batch: ray generation + trace + ordered accumulate + tonemap of the whole image 
 pixel (the reference's DrawBitmap bracket, spheres-app.cpp:20-26, minus its Direct2D blit).
 Inputs (scene tables) are resident in HBM before the timed region starts.
 
-N = 1 : spp = 128                       (BASELINE.json configs[1])
-N > 1 : spp = 128 * N, image rows sharded cyclically across ranks, one RCCL gather of the strips
+--config c2 (default): BASELINE.json configs[1], 1200x800 spp 128 per GPU.
+        N > 1: spp = 128 * N, image rows sharded cyclically across ranks, one RCCL gather of the strips
         to rank 0 per step (configs[2] is N = 8: spp 1024).  Per-GPU work is constant: weak scaling.
+--config c4: configs[3], cover scene, aperture 2.0, 1920x1080, spp 512 (divergent lens sampling).
+--config c5: configs[4], grid10k (10,004 spheres), 4096x4096, spp 64 (the bounds-hierarchy scan).
+The line has the same shape for every config; the driver's headline run is the default.
 
 Launch: python bench.py --gpus 1 ...   or
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                --master-port P bench.py --gpus N --steps K --warmup W
 Rank 0 prints ONE JSON line.
+
+roofline: the trace kernel is bound by VALU ISSUE (the matrix cores share the SIMD's
+issue port).  `achieved` = executed VALU lane-operations per launch (SQ_THREAD_CYCLES_VALU = SQ_INSTS_VALU x 64 x
+lane utilisation, from the committed rocprofv3 --pmc passes of this same command, profiles/r02_pmc_summary*.json)
+divided by the launch duration measured LIVE in this run with HIP events on the kernel's stream; `peak` = 78.6 T
+lane-op/s (256 CU x 4 SIMD x 64 lanes / 2 cycles x 2.4 GHz).  The instruction counts are a property of (kernel
+binary, workload): the PMC summary records the hash of the kernel sources it was taken from, and the roofline object
+is withheld (frac = null, error set, warning on stderr) when that hash is not the one of the library benchmarked.
+SURVEY.md §8(d)'s algorithmic unit (18 flop x N spheres per list scan) is reported separately as `cull_factor` =
+algorithmic flops / executed lane-operations: how much of the exhaustive scan the filters avoid.
 """
 import argparse
 import json
@@ -25,17 +38,33 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W_IMG, H_IMG, SPP_PER_GPU, DEPTH = 1200, 800, 128, 50
+DEPTH = 50
 SCENE_SEED, RENDER_SEED = 1, 1
-PEAK_VALU_TFLOPS = 78.6    # fp32 VALU without FMA: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md: 157.3 TF is the FMA figure)
-PEAK_HBM_GBS = 8000.0      # HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured float4 copy
+CONFIGS = {
+    # name: scene, W, H, spp per GPU, aperture (-1 = the scene's own), metric text, PMC summary
+    "c2": dict(scene="cover", W=1200, H=800, spp=128, aperture=-1.0,
+               metric="Msamples/sec (WxHxspp/s), 1200x800 cover scene spp=128 d=50", pmc="r02_pmc_summary.json"),
+    "c4": dict(scene="cover", W=1920, H=1080, spp=512, aperture=2.0,
+               metric="Msamples/sec (WxHxspp/s), 1920x1080 cover scene aperture=2.0 spp=512 d=50", pmc="r02_pmc_summary_c4.json"),
+    "c5": dict(scene="grid10k", W=4096, H=4096, spp=64, aperture=-1.0,
+               metric="Msamples/sec (WxHxspp/s), 4096x4096 grid10k scene (10,004 spheres) spp=64 d=50", pmc="r02_pmc_summary_c5.json"),
+}
+PEAK_VALU_TLANEOPS = 78.6   # 256 CU x 4 SIMD x 64 lanes / 2 cycles per wave-instruction x 2.4 GHz (MI355X_MICROARCH.md: SIMD-32, 2 cycles)
 FLOPS_PER_SPHERE_TEST = 18  # Sphere::Intersect up to the discriminant: 9 mul + 9 add/sub
-BYTES_PER_SPHERE_TEST = 16  # one (cx,cy,cz,r^2) record
 
 
-def cpu_baseline(target_seconds=15.0):
+def kernel_sources_hash():
+    """Identity of the device code: sha256 over the files librt_hip.so is compiled from (the .so itself is not tracked)."""
+    import __graft_entry__ as g
+    csrc = os.path.join(ROOT, "cpuraytracer_amd", "csrc")
+    files = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".h", ".hip")) or f == "Makefile"]
+    files.append(os.path.join(ROOT, "include", "rt_api.h"))
+    return g._sources_hash(files)
+
+
+def cpu_baseline(cfg, target_seconds=15.0):
     """The oracle (CPU restatement; kind 'port') timed on this box's host cores on a bounded sample of
-    the same workload: the full 1200x800 cover frame at a reduced spp (cost is exactly linear in spp),
+    the same workload: the full frame at a reduced spp (cost is exactly linear in spp),
     BvhNode traversal as in the reference, std::thread workers."""
     from oracle import oracle_py as O
     try:
@@ -44,22 +73,62 @@ def cpu_baseline(target_seconds=15.0):
         avail = os.cpu_count() or 1
     # a one-GPU box's CPU share is 16 cores; RT_CPU_BASELINE_THREADS overrides
     cores = int(os.environ.get("RT_CPU_BASELINE_THREADS", min(avail, 16)))
-    sc = O.build_scene("cover", SCENE_SEED, W_IMG / float(H_IMG))
+    W, H = cfg["W"], cfg["H"]
+    if W * H > 2000000:  # C5: a 1024x1024 crop-equivalent frame of the same scene and camera keeps the sample bounded
+        W, H = 1024, 1024
+    sc = O.build_scene(cfg["scene"], SCENE_SEED, cfg["W"] / float(cfg["H"]), cfg["aperture"])
     orc = O.Oracle()
     orc.upload(sc)
     t0 = time.perf_counter()
-    st = orc.render(W_IMG, H_IMG, 1, 2, DEPTH, RENDER_SEED, accel=O.ACCEL_BVH, threads=cores)
+    st = orc.render(W, H, 1, 2, DEPTH, RENDER_SEED, accel=O.ACCEL_BVH, threads=cores)
     orc.resolve()
     t1 = time.perf_counter() - t0
-    spp = int(max(1, min(SPP_PER_GPU, round(target_seconds / max(t1, 1e-3)))))
+    spp = int(max(1, min(cfg["spp"], round(target_seconds / max(t1, 1e-3)))))
     if spp > 1:
         t0 = time.perf_counter()
-        st = orc.render(W_IMG, H_IMG, 1, 1 + spp, DEPTH, RENDER_SEED, accel=O.ACCEL_BVH, threads=cores)
+        st = orc.render(W, H, 1, 1 + spp, DEPTH, RENDER_SEED, accel=O.ACCEL_BVH, threads=cores)
         orc.resolve()
         t1 = time.perf_counter() - t0
     return {"value": st.samples / t1 / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "cover scene %dx%d depth %d at spp=%d (of %d), BvhNode traversal, %d std::thread workers, %.1f s"
-                      % (W_IMG, H_IMG, DEPTH, spp, SPP_PER_GPU, cores, t1)}
+            "sample": "%s scene %dx%d depth %d at spp=%d (of %d), BvhNode traversal, %d std::thread workers, %.1f s"
+                      % (cfg["scene"], W, H, DEPTH, spp, cfg["spp"], cores, t1)}
+
+
+def roofline_object(cfg, kernel_name, avg_ms, avg_trav, n_spheres, src_hash):
+    """Executed-work roofline of the trace kernel (module docstring)."""
+    rl = {"bound": "valu-issue", "kernel": kernel_name, "achieved": None, "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",
+          "frac": None, "traffic": None, "launch_ms": avg_ms, "pmc_source": "profiles/" + cfg["pmc"],
+          "kernel_sources_sha256": src_hash}
+    path = os.path.join(ROOT, "profiles", cfg["pmc"])
+    try:
+        d = json.load(open(path))
+    except Exception as e:  # no profile for this config yet
+        rl["error"] = "no PMC summary (%s): run tools/profile_round.sh" % e
+        return rl, None
+    if d.get("kernel_sources_sha256") != src_hash:
+        rl["error"] = ("PMC summary %s was taken from kernel sources %s..., this library is %s...: re-run tools/profile_round.sh"
+                       % (cfg["pmc"], str(d.get("kernel_sources_sha256"))[:12], src_hash[:12]))
+        print("bench.py: WARNING: " + rl["error"], file=sys.stderr, flush=True)
+        return rl, None
+    t = d["raw_counters"]["trace"]
+    k = d["derived_trace_kernel"]
+    launches = max(1, int(k.get("launches_in_pmc_pass", 1)))
+    lane_ops = t["SQ_THREAD_CYCLES_VALU"] / launches   # active lanes summed over the VALU wave-instructions of one launch
+    insts = t["SQ_INSTS_VALU"] / launches
+    achieved = lane_ops / (avg_ms * 1e-3) / 1e12
+    rl.update({
+        "achieved": achieved, "frac": achieved / PEAK_VALU_TLANEOPS,
+        "traffic": k.get("hbm_bytes_per_launch"),
+        "valu_wave_insts_per_launch": insts, "lane_utilisation": lane_ops / (insts * 64.0),
+        # issue-slot view: 2 cycles per wave-instruction on a SIMD-32, 1024 SIMDs, at the clock the PMC pass measured
+        "issue_slot_frac": insts * 2.0 / (1024.0 * avg_ms * 1e-3 * k["effective_clock_GHz"] * 1e9),
+        "clock_GHz_in_pmc_pass": k["effective_clock_GHz"], "pmc_launch_ms": k["launch_ms_rocprof_avg"],
+        "note": "achieved = SQ_THREAD_CYCLES_VALU per launch (rocprofv3 --pmc, committed) / launch_ms (HIP events, this run); "
+                "frac x (1/lane_utilisation) = fraction of VALU issue slots used at 2.4 GHz",
+    })
+    cull = FLOPS_PER_SPHERE_TEST * avg_trav * n_spheres / lane_ops
+    return rl, {"value": cull, "algorithmic": "18 flop x %d spheres x %.0f list scans per launch (SURVEY.md 8d) / executed VALU lane-operations"
+                                              % (n_spheres, avg_trav)}
 
 
 def main():
@@ -67,8 +136,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    W_IMG, H_IMG, SPP_PER_GPU = cfg["W"], cfg["H"], cfg["spp"]
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -109,7 +181,7 @@ def main():
     stream = torch.cuda.Stream()  # a real (non-null) HIP stream: kernels, copies, events and the gather are ordered on it
     torch.cuda.set_stream(stream)
     r.set_stream(stream.cuda_stream)
-    sc = scenes.build_scene("cover", SCENE_SEED, W_IMG, H_IMG)
+    sc = scenes.build_scene(cfg["scene"], SCENE_SEED, W_IMG, H_IMG, aperture=cfg["aperture"])
     r.upload(sc)  # scene resident in HBM before the timed region
     rs = D.shard_rowset(H_IMG, rank, N)
     rows = D.local_rows(H_IMG, rank, N)
@@ -158,9 +230,6 @@ def main():
     n_spheres = sc.n
     avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
     avg_trav = sum(trav) / max(1, len(trav))
-    tests = avg_trav * n_spheres  # ray-sphere tests per launch of rt_trace_kernel on this rank
-    achieved_tflops = FLOPS_PER_SPHERE_TEST * tests / (avg_ms * 1e-3) / 1e12
-    achieved_gbs = BYTES_PER_SPHERE_TEST * tests / (avg_ms * 1e-3) / 1e9
 
     if rank == 0:
         total_samples = W_IMG * H_IMG * spp
@@ -169,43 +238,28 @@ def main():
         # assembling the gathered strips is outside the timed region (host side de-interleave for the PPM)
         full = D.assemble([p.cpu().numpy() for p in parts_l], H_IMG, N)
         assert full.shape == (H_IMG, W_IMG, 3)
-        traffic, pmc_note = None, "profiles/r01_pmc_summary.json"
-        tr_path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tr_path):
-            try:
-                traffic = json.load(open(tr_path)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        try:  # executed-instruction view of the same kernel from the committed PMC passes (tools/profile_round.sh)
-            d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["derived_trace_kernel"]
-            pmc_note = ("profiles/r01_pmc_summary.json (VALU issue ~%.0f %% busy, matrix cores ~%.0f %%, lane utilisation %.2f, %.3g VALU wave-instructions per launch)"
-                        % (100 * d["valu_issue_busy_estimate"], 100 * d["mfma_busy"], d["valu_lane_utilization"], d["valu_insts_per_launch"]))
-        except Exception:
-            pass
+        if os.environ.get("RT_BENCH_DUMP_LDR"):  # tests: the gathered image of the last step
+            import numpy as np
+            np.save(os.environ["RT_BENCH_DUMP_LDR"], full)
+        kernel_name = ("rt_trace_kernel<bounds hierarchy, 1024 threads, matrix-core top level + pooled descent>" if args.config == "c5"
+                       else "rt_trace_kernel<LDS tables, 1024 threads, matrix-core filter, path cache>")
+        roofline, cull = roofline_object(cfg, kernel_name, avg_ms, avg_trav, n_spheres, kernel_sources_hash())
         out = {
-            "metric": "Msamples/sec (WxHxspp/s), 1200x800 cover scene spp=128 d=50",
+            "metric": cfg["metric"],
             "value": value, "unit": "Msamples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share GPUs over gloo, not a measurement)" if rehearsal else ""),
-            "config": {"workload": "RTIOW cover scene (%d spheres, scene seed %d) %dx%d spp=%d depth=%d, render seed %d; "
+            "config": {"workload": "%s scene (%d spheres, scene seed %d) %dx%d spp=%d depth=%d%s, render seed %d; "
                                    "rows sharded cyclically over %d GPU(s) in 4-row blocks, RCCL gather of strips to rank 0"
-                                   % (n_spheres, SCENE_SEED, W_IMG, H_IMG, spp, DEPTH, RENDER_SEED, N),
-                       "spp_per_gpu": SPP_PER_GPU, "samples_per_step": total_samples,
-                       "traversals_per_sample": avg_trav / (W_IMG * rows * spp)},
-            "roofline": {"bound": "valu", "kernel": "rt_trace_kernel<LDS tables, 1024 threads, matrix-core filter, path cache>",
-                         "achieved": achieved_tflops, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tflops / PEAK_VALU_TFLOPS, "traffic": traffic, "launch_ms": avg_ms,
-                         "algorithmic": "18 flop x %d spheres x %.0f list scans per launch (SURVEY.md 8d; unfused fp32, peak = 157.3/2)"
-                                        % (n_spheres, avg_trav),
-                         "note": "frac > 1 is real: ALGORITHMIC flops of exhaustive list scans (SURVEY 8d) over the time of a kernel that "
-                                 "culls (split-bf16 group-bound filter on the matrix cores, exact VALU resolve of the survivors, shadow "
-                                 "rays answered by an exact footprint index). Executed-instruction view: " + pmc_note},
-            "hbm_read_equivalent": {"bound": "hbm", "achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                    "frac": achieved_gbs / PEAK_HBM_GBS,
-                                    "note": "16 B sphere record x tests / kernel time; served from LDS, so it may exceed the HBM roofline"},
+                                   % (cfg["scene"], n_spheres, SCENE_SEED, W_IMG, H_IMG, spp, DEPTH,
+                                      (" aperture=%.1f" % cfg["aperture"]) if cfg["aperture"] >= 0 else "", RENDER_SEED, N),
+                       "name": args.config, "spp": spp, "spp_per_gpu": SPP_PER_GPU, "samples_per_step": total_samples,
+                       "traversals_per_sample": avg_trav / (W_IMG * rows * spp), "passes": st_last.passes},
+            "roofline": roofline,
+            "cull_factor": cull,
         }
         if N == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
