@@ -57,7 +57,7 @@ def kernel_sources_hash():
     """Identity of the device code: sha256 over the files librt_hip.so is compiled from (the .so itself is not tracked)."""
     import __graft_entry__ as g
     csrc = os.path.join(ROOT, "cpuraytracer_amd", "csrc")
-    files = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".h", ".hip")) or f == "Makefile"]
+    files = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".h", ".hip", ".inc")) or f == "Makefile"]
     files.append(os.path.join(ROOT, "include", "rt_api.h"))
     return g._sources_hash(files)
 

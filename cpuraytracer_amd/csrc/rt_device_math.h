@@ -109,33 +109,37 @@ RT_DEV float fresnel_term(float c, float n) {
 }
 
 // ------------------------------------------------------------- elementary functions (f64 kernels)
+// Contract (oracle/dxmath_restate.h restates it independently): binary64 kernels with EXPLICIT fused
+// multiply-adds (__builtin_fma: one rounding, identical on gfx950's v_fma_f64 and on the host's FMA unit / libm fma),
+// table lookups into rt_math_tables.inc (generated, tools/gen_math_tables.py) and one final rounding to binary32.
+// The FIRST step of every Horner chain is an unfused multiply + add: a fused one would have two literal operands, and
+// gfx950's VOP3 encoding reads at most one scalar/literal per instruction -- the second constant would sit in a VGPR
+// pair for the whole persistent loop (measured: 10 spilled VGPRs).
+// gfx950 runs f64 VALU at half the f32 rate, so the kernels are short: sincos 24 f64 operations (64-entry table of
+// sin/cos(j pi/32), degree-7/8 remainders), pow 36 (47-entry reciprocal/log2 table, degree-9 log1p; 33-entry 2^(j/32)
+// table, degree-6 exp) -- the round-1 kernels (long division, degree-21/13 series without fma) were 76 and 110.
+RT_DEV double f64_of_bits(unsigned long long b) { return __builtin_bit_cast(double, b); }
+
+// x >= 0.  j = rint(x * 32/pi); r = x - j pi/32 (two-term); sin/cos(x) = S_j cos r + C_j sin r, C_j cos r - S_j sin r.
+// At the multiples of pi/2 the table holds exact 0 / +-1, so results near the zeros keep full relative accuracy.
 RT_DEV void sincos_f64(float xf, double& s_out, double& c_out) {
-    const double TWO_OVER_PI = 0.63661977236758138243;
-    const double PIO2_HI = 1.57079632679489655800e+00;
-    const double PIO2_LO = 6.12323399573676603587e-17;
+#include "rt_math_tables.inc"
     const double x = (double)xf;
-    const int k = (int)(x * TWO_OVER_PI + 0.5);  // x >= 0
-    const double kd = (double)k;
-    double r = x - kd * PIO2_HI;
-    r = r - kd * PIO2_LO;
+    const double jd = __builtin_rint(x * 10.185916357881301);  // 32/pi
+    const int j = (int)jd & 63;
+    double r = __builtin_fma(-jd, 0.09817477042468103, x);       // pi/32 hi = 0x3FB921FB54442D18
+    r = __builtin_fma(-jd, 3.8270212473354788e-18, r);           // pi/32 lo = 0x3C51A62633145C07
     const double z = r * r;
-    double ps = 1.58969099521155010221e-10;
-    ps = ps * z + -2.50507602534068634195e-08;
-    ps = ps * z + 2.75573137070700676789e-06;
-    ps = ps * z + -1.98412698298579493134e-04;
-    ps = ps * z + 8.33333333332248946124e-03;
-    ps = ps * z + -1.66666666666666324348e-01;
-    const double sr = r + (r * z) * ps;
-    double pc = -1.13596475577881948265e-11;
-    pc = pc * z + 2.08757232129817482790e-09;
-    pc = pc * z + -2.75573143513906633035e-07;
-    pc = pc * z + 2.48015872894767294178e-05;
-    pc = pc * z + -1.38888888888741095749e-03;
-    pc = pc * z + 4.16666666666666019037e-02;
-    const double cr = 1.0 - (0.5 * z - (z * z) * pc);
-    const int quad = k & 3;
-    s_out = (quad == 0) ? sr : (quad == 1) ? cr : (quad == 2) ? -sr : -cr;
-    c_out = (quad == 0) ? cr : (quad == 1) ? -sr : (quad == 2) ? -cr : sr;
+    double ps = z * -1.984126984126984e-04 + 8.333333333333333e-03;  // -1/5040, 1/120
+    ps = __builtin_fma(z, ps, -1.6666666666666666e-01);                            // -1/6
+    const double sr = __builtin_fma(r * z, ps, r);
+    double pc = z * 2.48015873015873e-05 + -1.388888888888889e-03;   // 1/40320, -1/720
+    pc = __builtin_fma(z, pc, 4.1666666666666664e-02);                            // 1/24
+    pc = __builtin_fma(z, pc, -0.5);
+    const double cr = __builtin_fma(z, pc, 1.0);
+    const double S = f64_of_bits(kSinCosTabBits[j][0]), C = f64_of_bits(kSinCosTabBits[j][1]);
+    s_out = __builtin_fma(C, sr, S * cr);
+    c_out = __builtin_fma(-S, sr, C * cr);
 }
 RT_DEV float rt_sinf(float x) { double s, c; sincos_f64(x, s, c); return (float)s; }
 RT_DEV float rt_cosf(float x) { double s, c; sincos_f64(x, s, c); return (float)c; }
@@ -143,6 +147,7 @@ RT_DEV float rt_tanf(float x) { double s, c; sincos_f64(x, s, c); return (float)
 
 // pow(x,y) = 2^(y*log2 x), x >= 0.
 RT_DEV float rt_powf(float xf, float yf) {
+#include "rt_math_tables.inc"
     if (yf == 0.f) return 1.f;
     if (!(xf > 0.f)) return 0.f;
     if (xf == 1.f) return 1.f;
@@ -152,6 +157,8 @@ RT_DEV float rt_powf(float xf, float yf) {
         const double x4 = x2 * x2;
         return (float)(x4 * x);
     }
+    // log2 x = e + log2 m, m in [sqrt(1/2), sqrt(2)); idx = rint((m - 1) 64), r = RN(1 / (1 + idx/64)), u = m r - 1 (|u| < 0.0113),
+    // log2 m = -log2 r + log1p(u) / ln 2.  idx == 0 has r = 1 exactly: no cancellation for x near 1.
     const uint64_t bits = __builtin_bit_cast(uint64_t, x);
     int e = (int)((bits >> 52) & 0x7ff) - 1023;
     double m = __builtin_bit_cast(double, (uint64_t)((bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL));
@@ -159,43 +166,35 @@ RT_DEV float rt_powf(float xf, float yf) {
         m = m * 0.5;
         e = e + 1;
     }
-    const double s = (m - 1.0) / (m + 1.0);
-    const double z = s * s;
-    double p = 0.047619047619047616404;
-    p = p * z + 0.052631578947368418131;
-    p = p * z + 0.058823529411764705066;
-    p = p * z + 0.066666666666666665741;
-    p = p * z + 0.076923076923076927347;
-    p = p * z + 0.090909090909090911614;
-    p = p * z + 0.11111111111111110494;
-    p = p * z + 0.14285714285714284921;
-    p = p * z + 0.2000000000000000111;
-    p = p * z + 0.33333333333333331483;
-    p = p * z + 1.0;
-    const double lnm = (2.0 * s) * p;
-    const double log2x = (double)e + lnm * 1.4426950408889633870;
+    const int idx = (int)__builtin_rint((m - 1.0) * 64.0);
+    const double rj = f64_of_bits(kLogTabBits[idx + 19][0]), lj = f64_of_bits(kLogTabBits[idx + 19][1]);
+    const double u = __builtin_fma(m, rj, -1.0);
+    double p = u * 1.1111111111111111e-01 + -0.125;      // u^9/9, -u^8/8
+    p = __builtin_fma(u, p, 1.4285714285714285e-01);                   // 1/7
+    p = __builtin_fma(u, p, -1.6666666666666666e-01);                  // -1/6
+    p = __builtin_fma(u, p, 0.2);
+    p = __builtin_fma(u, p, -0.25);
+    p = __builtin_fma(u, p, 3.3333333333333331e-01);                   // 1/3
+    p = __builtin_fma(u, p, -0.5);
+    const double lp = __builtin_fma(u * u, p, u);                      // log1p(u)
+    const double log2x = __builtin_fma(lp, 1.4426950408889634, (double)e + lj);  // 1/ln 2
     const double t = (double)yf * log2x;
     if (t < -160.0) return 0.f;
     if (t > 160.0) return __builtin_inff();
-    const int k = (int)(t + (t >= 0.0 ? 0.5 : -0.5));
-    const double f = t - (double)k;
-    const double g = f * 0.69314718055994528623;
-    double q = 1.6059043836821613341e-10;
-    q = q * g + 2.0876756987868100187e-09;
-    q = q * g + 2.5052108385441720224e-08;
-    q = q * g + 2.7557319223985892511e-07;
-    q = q * g + 2.7557319223985888276e-06;
-    q = q * g + 2.4801587301587301566e-05;
-    q = q * g + 1.9841269841269841253e-04;
-    q = q * g + 1.3888888888888889419e-03;
-    q = q * g + 8.3333333333333332177e-03;
-    q = q * g + 4.1666666666666664354e-02;
-    q = q * g + 1.6666666666666665741e-01;
-    q = q * g + 0.5;
-    q = q * g + 1.0;
-    q = q * g + 1.0;
-    const double scale = __builtin_bit_cast(double, (uint64_t)(1023 + k) << 52);
-    return (float)(q * scale);
+    // 2^t = 2^k 2^(j/32) e^(h ln 2), k = rint(t), j = rint(32 (t - k)) in [-16, 16], |h| <= 1/64
+    const double kd = __builtin_rint(t);
+    const double f = t - kd;
+    const double jd = __builtin_rint(f * 32.0);
+    const double h = __builtin_fma(jd, -0.03125, f);
+    const double g = h * 0.69314718055994531;  // ln 2
+    double q = g * 1.3888888888888889e-03 + 8.3333333333333332e-03;  // 1/720, 1/120
+    q = __builtin_fma(g, q, 4.1666666666666664e-02);                                // 1/24
+    q = __builtin_fma(g, q, 1.6666666666666666e-01);                                // 1/6
+    q = __builtin_fma(g, q, 0.5);
+    q = __builtin_fma(g, q, 1.0);
+    q = __builtin_fma(g, q, 1.0);
+    const double w = f64_of_bits(kExp2TabBits[(int)jd + 16]) * q;
+    return (float)__builtin_ldexp(w, (int)kd);
 }
 
 // ----------------------------------------------------------------------- quasi-random.cpp

@@ -57,7 +57,7 @@ def build(force=False):
     from the one recorded at the last build (content, not mtime: snapshots need not keep modification times)."""
     import glob
     import hashlib
-    srcs = sorted(glob.glob(os.path.join(_HERE, "*.cpp")) + glob.glob(os.path.join(_HERE, "*.h")) +
+    srcs = sorted(glob.glob(os.path.join(_HERE, "*.cpp")) + glob.glob(os.path.join(_HERE, "*.h")) + glob.glob(os.path.join(_HERE, "*.inc")) +
                   [os.path.join(_HERE, "Makefile"), os.path.join(_HERE, "..", "include", "rt_api.h")])
     h = hashlib.sha256()
     for p in srcs:
