@@ -556,20 +556,31 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
         tp.ray_cache_off16 = (uint32_t)(ldsBytes / 16);
         ldsBytes += (size_t)wavesPerBlock * rtd::kRayCacheBytes;
     }
-#define RT_LAUNCH_C(LDS, T, M, C)                                                                                                  \
+    if (std::getenv("RT_VERBOSE"))
+        std::fprintf(stderr, "rt_trace launch: tree=%d flat=%d ldsTables=%d blocks=%u threads=%u lds=%zu B (cand %zu, tables %zu, leaf %zu, ops %zu, sg %zu, tree %zu, cache %s)\n",
+                     (int)tree, (int)flat, (int)ldsTables, blocks, ctx->blockThreads, ldsBytes, candBytes, ldsTables ? lds : (size_t)0, flat ? leafBytes : (size_t)0,
+                     (flat || tree) ? MfmaOpsBytesFor(topCnt) : (size_t)0, sgBytes, treeBytes, tp.ray_cache_off16 ? "yes" : "no");
+    // flat variant with the hit-processing tables provably in LDS (typed pointers: no flat loads) when they all fit
+    const bool hitLds = flat && tp.mats_in_lds && (sgBytes != 0 || !tp.sg_enabled);
+#define RT_LAUNCH_K(KERNEL)                                                                                                   \
     do {                                                                                                                      \
-        const void* fn_ = reinterpret_cast<const void*>(&rtd::rt_trace_kernel<LDS, T, M, C>);                                  \
+        const void* fn_ = reinterpret_cast<const void*>(&KERNEL);                                                             \
         size_t& set_ = ctx->ldsAttr[fn_];  /* the attribute call costs host time on launch-bound 1-spp frames: only on change */ \
         if (ldsBytes > 48 * 1024 && set_ != ldsBytes) {                                                                       \
             RT_HIP(hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));                      \
             set_ = ldsBytes;                                                                                                  \
         }                                                                                                                     \
-        hipLaunchKernelGGL((rtd::rt_trace_kernel<LDS, T, M, C>), dim3(blocks), dim3(T), ldsBytes, ctx->stream, tp);           \
+        hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(ctx->blockThreads), ldsBytes, ctx->stream, tp);                         \
     } while (0)
-#define RT_LAUNCH(LDS, T, M)                        \
-    do {                                            \
-        if (tp.ray_cache_off16) RT_LAUNCH_C(LDS, T, M, true); \
-        else RT_LAUNCH_C(LDS, T, M, false);         \
+#define RT_LAUNCH(LDS, T, M)                                                                        \
+    do {                                                                                            \
+        if ((M) == 1 && hitLds) {                                                                   \
+            if (tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<LDS, T, M, true, (M) == 1>));  \
+            else RT_LAUNCH_K((rtd::rt_trace_kernel<LDS, T, M, false, (M) == 1>));                    \
+        } else {                                                                                    \
+            if (tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<LDS, T, M, true, false>));    \
+            else RT_LAUNCH_K((rtd::rt_trace_kernel<LDS, T, M, false, false>));                      \
+        }                                                                                           \
     } while (0)
 #define RT_LAUNCH_T(LDS, M)                                            \
     do {                                                               \
@@ -583,7 +594,7 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     else RT_LAUNCH_T(false, 0);
 #undef RT_LAUNCH_T
 #undef RT_LAUNCH
-#undef RT_LAUNCH_C
+#undef RT_LAUNCH_K
     RT_HIP(hipGetLastError());
     return RT_OK;
 }

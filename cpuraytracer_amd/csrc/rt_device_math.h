@@ -120,10 +120,35 @@ RT_DEV float fresnel_term(float c, float n) {
 // table, degree-6 exp) -- the round-1 kernels (long division, degree-21/13 series without fma) were 76 and 110.
 RT_DEV double f64_of_bits(unsigned long long b) { return __builtin_bit_cast(double, b); }
 
+// A binary64 literal for the Horner chains below.  gfx950's VOP3 encoding has no 64-bit literals, so the compiler keeps
+// each coefficient in a register pair; left alone it hoists a dozen of them into VGPR pairs for the whole persistent loop
+// (spills) and copies one into the destination before every v_fmac_f64.  The empty asm pins the coefficient to a scalar
+// pair right where it is used: two s_mov_b32 on the scalar unit, then one v_fma_f64 with a scalar addend.
+#if defined(__HIP_DEVICE_COMPILE__)
+RT_DEV double kf64(double c) {
+    asm volatile("" : "+s"(c));
+    return c;
+}
+#else
+RT_DEV double kf64(double c) { return c; }
+#endif
+
+// Where a caller reads the contract's tables from: the constant copy in the code object (default), or the copy the trace
+// kernel stages into LDS (an L2 round trip per lookup would otherwise sit in front of every pow and sincos).
+struct MathTabs {
+    const unsigned long long* log;     // [47][2]  r = RN(1 / (1 + idx/64)), l = RN(-log2 r)
+    const unsigned long long* exp2;    // [33]     RN(2^(j/32)), j = -16 .. 16
+    const unsigned long long* sincos;  // [64][2]  RN(sin(j pi/32)), RN(cos(j pi/32))
+};
+constexpr unsigned kMathTabWords = 47 * 2 + 33 + 64 * 2;  // 255 64-bit words
+RT_DEV MathTabs default_math_tabs() {
+#include "rt_math_tables.inc"
+    return MathTabs{&kLogTabBits[0][0], &kExp2TabBits[0], &kSinCosTabBits[0][0]};
+}
+
 // x >= 0.  j = rint(x * 32/pi); r = x - j pi/32 (two-term); sin/cos(x) = S_j cos r + C_j sin r, C_j cos r - S_j sin r.
 // At the multiples of pi/2 the table holds exact 0 / +-1, so results near the zeros keep full relative accuracy.
-RT_DEV void sincos_f64(float xf, double& s_out, double& c_out) {
-#include "rt_math_tables.inc"
+RT_DEV void sincos_f64(float xf, double& s_out, double& c_out, const MathTabs& T) {
     const double x = (double)xf;
     const double jd = __builtin_rint(x * 10.185916357881301);  // 32/pi
     const int j = (int)jd & 63;
@@ -131,23 +156,23 @@ RT_DEV void sincos_f64(float xf, double& s_out, double& c_out) {
     r = __builtin_fma(-jd, 3.8270212473354788e-18, r);           // pi/32 lo = 0x3C51A62633145C07
     const double z = r * r;
     double ps = z * -1.984126984126984e-04 + 8.333333333333333e-03;  // -1/5040, 1/120
-    ps = __builtin_fma(z, ps, -1.6666666666666666e-01);                            // -1/6
+    ps = __builtin_fma(z, ps, kf64(-1.6666666666666666e-01));                            // -1/6
     const double sr = __builtin_fma(r * z, ps, r);
     double pc = z * 2.48015873015873e-05 + -1.388888888888889e-03;   // 1/40320, -1/720
-    pc = __builtin_fma(z, pc, 4.1666666666666664e-02);                            // 1/24
+    pc = __builtin_fma(z, pc, kf64(4.1666666666666664e-02));                            // 1/24
     pc = __builtin_fma(z, pc, -0.5);
     const double cr = __builtin_fma(z, pc, 1.0);
-    const double S = f64_of_bits(kSinCosTabBits[j][0]), C = f64_of_bits(kSinCosTabBits[j][1]);
+    const double S = f64_of_bits(T.sincos[2 * j]), C = f64_of_bits(T.sincos[2 * j + 1]);
     s_out = __builtin_fma(C, sr, S * cr);
     c_out = __builtin_fma(-S, sr, C * cr);
 }
+RT_DEV void sincos_f64(float xf, double& s_out, double& c_out) { sincos_f64(xf, s_out, c_out, default_math_tabs()); }
 RT_DEV float rt_sinf(float x) { double s, c; sincos_f64(x, s, c); return (float)s; }
 RT_DEV float rt_cosf(float x) { double s, c; sincos_f64(x, s, c); return (float)c; }
 RT_DEV float rt_tanf(float x) { double s, c; sincos_f64(x, s, c); return (float)(s / c); }
 
 // pow(x,y) = 2^(y*log2 x), x >= 0.
-RT_DEV float rt_powf(float xf, float yf) {
-#include "rt_math_tables.inc"
+RT_DEV float rt_powf(float xf, float yf, const MathTabs& T) {
     if (yf == 0.f) return 1.f;
     if (!(xf > 0.f)) return 0.f;
     if (xf == 1.f) return 1.f;
@@ -167,14 +192,14 @@ RT_DEV float rt_powf(float xf, float yf) {
         e = e + 1;
     }
     const int idx = (int)__builtin_rint((m - 1.0) * 64.0);
-    const double rj = f64_of_bits(kLogTabBits[idx + 19][0]), lj = f64_of_bits(kLogTabBits[idx + 19][1]);
+    const double rj = f64_of_bits(T.log[2 * (idx + 19)]), lj = f64_of_bits(T.log[2 * (idx + 19) + 1]);
     const double u = __builtin_fma(m, rj, -1.0);
     double p = u * 1.1111111111111111e-01 + -0.125;      // u^9/9, -u^8/8
-    p = __builtin_fma(u, p, 1.4285714285714285e-01);                   // 1/7
-    p = __builtin_fma(u, p, -1.6666666666666666e-01);                  // -1/6
-    p = __builtin_fma(u, p, 0.2);
-    p = __builtin_fma(u, p, -0.25);
-    p = __builtin_fma(u, p, 3.3333333333333331e-01);                   // 1/3
+    p = __builtin_fma(u, p, kf64(1.4285714285714285e-01));                   // 1/7
+    p = __builtin_fma(u, p, kf64(-1.6666666666666666e-01));                  // -1/6
+    p = __builtin_fma(u, p, kf64(0.2));
+    p = __builtin_fma(u, p, kf64(-0.25));
+    p = __builtin_fma(u, p, kf64(3.3333333333333331e-01));                   // 1/3
     p = __builtin_fma(u, p, -0.5);
     const double lp = __builtin_fma(u * u, p, u);                      // log1p(u)
     const double log2x = __builtin_fma(lp, 1.4426950408889634, (double)e + lj);  // 1/ln 2
@@ -188,14 +213,15 @@ RT_DEV float rt_powf(float xf, float yf) {
     const double h = __builtin_fma(jd, -0.03125, f);
     const double g = h * 0.69314718055994531;  // ln 2
     double q = g * 1.3888888888888889e-03 + 8.3333333333333332e-03;  // 1/720, 1/120
-    q = __builtin_fma(g, q, 4.1666666666666664e-02);                                // 1/24
-    q = __builtin_fma(g, q, 1.6666666666666666e-01);                                // 1/6
+    q = __builtin_fma(g, q, kf64(4.1666666666666664e-02));                                // 1/24
+    q = __builtin_fma(g, q, kf64(1.6666666666666666e-01));                                // 1/6
     q = __builtin_fma(g, q, 0.5);
     q = __builtin_fma(g, q, 1.0);
     q = __builtin_fma(g, q, 1.0);
-    const double w = f64_of_bits(kExp2TabBits[(int)jd + 16]) * q;
+    const double w = f64_of_bits(T.exp2[(int)jd + 16]) * q;
     return (float)__builtin_ldexp(w, (int)kd);
 }
+RT_DEV float rt_powf(float xf, float yf) { return rt_powf(xf, yf, default_math_tabs()); }
 
 // ----------------------------------------------------------------------- quasi-random.cpp
 // Random::HaltonSample (quasi-random.cpp:3-16) with a 32-bit index: every index on the path is

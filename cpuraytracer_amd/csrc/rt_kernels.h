@@ -94,7 +94,11 @@ struct SceneTabs {
 // LDS to tabBase (16-byte aligned pieces: scan | one-sphere bounds (flat matrix-core scan only) | orig | materials (48 B =
 // 3 float4) | radii | filter operands | shadow index; tree mode: operands | all levels of bounds) and build the filter's
 // operand image.  Every thread of the workgroup must call it.
-template <bool kLds, int kScan>
+// kHitLds (flat matrix-core variant only): the material table and the shadow index are in LDS too, and their pointers
+// are assigned unconditionally so that the compiler can prove the address space -- a pointer that is LDS or global
+// depending on a run-time flag becomes a FLAT load, and every flat load waits for vmcnt(0) AND lgkmcnt(0), i.e. also
+// for the previous iteration's sample stores.  The host launches it only when p.mats_in_lds and (p.sg_in_lds or no index).
+template <bool kLds, int kScan, bool kHitLds = false>
 RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
     constexpr bool kMfma = kScan != 0;
     T.scan = p.scan;
@@ -117,7 +121,7 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
         float4* ldsLeaf = ldsScan + p.n_padded;
         uint32_t* ldsOrig = reinterpret_cast<uint32_t*>(ldsLeaf + (kScan == 1 ? p.n_padded : 0u));
         float4* ldsMat = reinterpret_cast<float4*>(ldsOrig + p.n_padded);  // n_padded is a multiple of 4
-        const uint32_t nMatLds = p.mats_in_lds ? p.n_padded : 0u;
+        const uint32_t nMatLds = (kHitLds || p.mats_in_lds) ? p.n_padded : 0u;
         float* ldsRad = reinterpret_cast<float*>(ldsMat + (size_t)nMatLds * 3);
         const float4* gMat = reinterpret_cast<const float4*>(p.mats);
         for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) {
@@ -131,7 +135,19 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
             float* ldsOps = ldsRad + p.n_padded;  // a multiple of 4
             build_mfma_operands(p.tree + p.level_off[topLevel], nTop, nTiles, ldsOps, threadIdx.x, blockDim.x);
             T.ops = ldsOps;
-            if (p.sg_enabled && p.sg_in_lds) {  // shadow index after the operand image
+            if (kHitLds) {
+                // typed LDS pointers, staged only when the scene has an index (the pointers are never read otherwise)
+                uint16_t* g = reinterpret_cast<uint16_t*>(ldsOps + (size_t)nTiles * kOpsPerTile);
+                const uint32_t nc = p.sg_nx * p.sg_ny + 1u;
+                if (p.sg_enabled) {
+                    for (uint32_t k = threadIdx.x; k < nc; k += blockDim.x) g[k] = p.sg_cell_start[k];
+                    for (uint32_t k = threadIdx.x; k < p.sg_nentries; k += blockDim.x) g[nc + k] = p.sg_entries[k];
+                    for (uint32_t k = threadIdx.x; k < p.sg_nglobal; k += blockDim.x) g[nc + p.sg_nentries + k] = p.sg_global[k];
+                }
+                T.sgCell = g;
+                T.sgEntries = g + nc;
+                T.sgGlobal = g + nc + p.sg_nentries;
+            } else if (p.sg_enabled && p.sg_in_lds) {  // shadow index after the operand image
                 uint16_t* g = reinterpret_cast<uint16_t*>(ldsOps + (size_t)nTiles * kOpsPerTile);
                 const uint32_t nc = p.sg_nx * p.sg_ny + 1u;
                 for (uint32_t k = threadIdx.x; k < nc; k += blockDim.x) g[k] = p.sg_cell_start[k];
@@ -147,7 +163,8 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
         T.orig = ldsOrig;
         if (kScan == 1) T.leaf = ldsLeaf;
         T.rad = ldsRad;
-        if (p.mats_in_lds) T.mats = reinterpret_cast<const rt_material*>(ldsMat);
+        if (kHitLds) T.mats = reinterpret_cast<const rt_material*>(ldsMat);
+        else if (p.mats_in_lds) T.mats = reinterpret_cast<const rt_material*>(ldsMat);
     } else if (kMfma) {
         // exact tables stay in global memory (L2); the top level's operand image and, when they fit, all bounds live in LDS
         float* ldsOps = reinterpret_cast<float*>(tabBase);
@@ -171,18 +188,30 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
 // max_depth+1 segments have finished.
 // kScan: 0 = VALU sign filter per group (any scene size), 1 = matrix-core filter over the groups (tables in LDS),
 // 2 = matrix-core filter over the top level of the bounds hierarchy + per-lane descent (tables through L2).
-template <bool kLds, int kThreads, int kScan, bool kCache>
+template <bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds = false>
 __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams p) {
     constexpr bool kMfma = kScan != 0;
     extern __shared__ float4 smem[];
     // [0, kConstBytes): the scene constants; then the per-wave regions; then the tables
     SceneConsts* ldsK = reinterpret_cast<SceneConsts*>(smem);
     if (threadIdx.x == 0) fill_consts(p, *ldsK);
+    // the elementary functions' tables behind the constants (log | exp2 | sincos, as MathTabs indexes them)
+    unsigned long long* ldsMath = reinterpret_cast<unsigned long long*>(smem + kSceneConstBytes / 16);
+    {
+        const MathTabs g = default_math_tabs();
+        for (uint32_t k = threadIdx.x; k < kMathTabWords; k += blockDim.x)
+            ldsMath[k] = k < 94u ? g.log[k] : (k < 127u ? g.exp2[k - 94u] : g.sincos[k - 127u]);
+    }
+#ifdef RT_NO_LDS_MATH
+    const MathTabs mt = default_math_tabs();
+#else
+    const MathTabs mt{ldsMath, ldsMath + 94, ldsMath + 127};
+#endif
     uint16_t* candBase = reinterpret_cast<uint16_t*>(smem + kConstBytes / 16);
     constexpr uint32_t kWaveRegion = kScan == 2 ? kWaveCandBytes : kWaveListBytes;  // the descent stack only exists in tree mode
     float4* tabBase = smem + kConstBytes / 16 + (kThreads / kWaveSize) * (kWaveRegion / 16);
     SceneTabs T;
-    stage_scene<kLds, kScan>(p, tabBase, T);  // ends with a workgroup barrier when it staged anything
+    stage_scene<kLds, kScan, kHitLds>(p, tabBase, T);  // ends with a workgroup barrier when it staged anything
     const float4* scanTab = T.scan;
     const uint32_t* origTab = T.orig;
     const float4* leafTab = T.leaf;
@@ -356,7 +385,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                 const V3 nrm = (pos - center) / radius;  // ray-tracing.cpp:58
                 V3 atten, local, localOcc, tex;
                 RT_STAMP(th0);
-                const bool scattered = scatter_only(m, rd, nrm, draws, atten, nextDir, tex);  // Scatter first: it draws (spheres-app.cpp:246)
+                const bool scattered = scatter_only(m, rd, nrm, draws, atten, nextDir, tex, mt);  // Scatter first: it draws (spheres-app.cpp:246)
                 RT_STAMP(th1);
                 const bool cont = (depth < p.max_depth) && scattered;  // spheres-app.cpp:247
                 const bool useIndex = K.sg_enabled && dot3(pos, pos) <= K.sg_p0sq;
@@ -364,7 +393,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                 if (useIndex) occluded = shadow_query(K, scanTab, sgCell, sgEntries, sgGlobal, pos, sunDir, aSun);
                 RT_STAMP(th2);
                 // the Blinn-Phong value (two normalisations, two pows) is only needed when the sun is visible or unknown
-                shade_value(K, m, tex, pos, nrm, !occluded, local, localOcc);
+                shade_value(K, m, tex, pos, nrm, !occluded, local, localOcc, mt);
                 RT_STAMP(th3);
 #ifdef RT_STAMPS
                 thA = th0;

@@ -103,8 +103,10 @@ struct SceneConsts {
     const float2* jitter_tab;
     const float2* lens_tab;
 };
-constexpr uint32_t kConstBytes = 256;  // LDS reserved for SceneConsts at the start of the dynamic image
-static_assert(sizeof(SceneConsts) <= kConstBytes, "SceneConsts must fit its LDS slot");
+constexpr uint32_t kSceneConstBytes = 256;                         // SceneConsts at the start of the dynamic LDS image ...
+constexpr uint32_t kConstBytes = kSceneConstBytes + 8 * 256;       // ... followed by the elementary functions' tables (255 words)
+static_assert(sizeof(SceneConsts) <= kSceneConstBytes, "SceneConsts must fit its LDS slot");
+static_assert(kMathTabWords <= 256, "math tables must fit their LDS slot");
 RT_DEV void fill_consts(const TraceParams& p, SceneConsts& k) {
     for (int i = 0; i < 3; ++i) {
         k.cam_o[i] = p.cam_o[i]; k.cam_x[i] = p.cam_x[i]; k.cam_y[i] = p.cam_y[i]; k.cam_oip[i] = p.cam_oip[i];
@@ -162,9 +164,12 @@ RT_DEV void gen_primary_ray(const P& p, uint32_t i, uint32_t j, uint32_t s, V3& 
     if (p.jitter_tab) {
         // the radical inverses depend on s (jitter) and s+i+j (lens) only: a per-pass device kernel
         // tabulates them so that a refilled lane does two 8-byte loads instead of four divide loops
-        const float2 jt = p.jitter_tab[s - p.s0];
-        const float2 lt = p.lens_tab[li - p.lens_k0];
-        jx = jt.x; jy = jt.y; lensx = lt.x; lensy = lt.y;
+        // the pointers may come out of LDS (SceneConsts): say that they point to global memory, or the loads become FLAT
+        // ones, which wait for vmcnt(0) and lgkmcnt(0) -- i.e. for the wave's outstanding sample stores as well
+        typedef const float __attribute__((address_space(1)))* GlobalF;
+        const GlobalF jt = (GlobalF)(p.jitter_tab + (s - p.s0));
+        const GlobalF lt = (GlobalF)(p.lens_tab + (li - p.lens_k0));
+        jx = jt[0]; jy = jt[1]; lensx = lt[0]; lensy = lt[1];
     } else {
         jx = halton(s, 2);
         jy = halton(s, 3);

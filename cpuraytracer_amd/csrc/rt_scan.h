@@ -253,6 +253,13 @@ RT_DEV void build_mfma_operands(const float4* __restrict__ bounds, uint32_t nGro
     }
 }
 
+// min(x, p) for p > 0 as ONE integer instruction: a negative float's pattern is a negative integer (below every
+// positive one) and positive floats order like their patterns.  (fminf would add a canonicalising v_max per operand.)
+RT_DEV float min_with_positive(float x, float p) {
+    const int xi = __float_as_int(x), pi = __float_as_int(p);
+    return __int_as_float(xi < pi ? xi : pi);
+}
+
 // Filter decision for this lane's 16 rows of one tile: the ray may hit the group unless F = b~^2 - t < 0 (t = a*cc~ - M)
 // or the group is surely behind the origin.  "Behind" = the origin is outside the inflated bound (t > 0, which already
 // includes the margin) and the centre is behind it by more than the rounding of b~ (b~ > bthr, bthr =
@@ -264,23 +271,24 @@ RT_DEV void mfma_post(const f32x16& Tb, const f32x16& Tg, float bthr, uint32_t& 
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const float t = Tg[e];  // a*cc~ - M: the per-ray constant is part of the contraction
-        const float f = __builtin_fmaf(Tb[e], Tb[e], -t);
-        const float u = bthr - Tb[e];  // negative <=> centre behind the origin
-        const uint32_t rej = __float_as_uint(f) | (__float_as_uint(u) & ~__float_as_uint(t));  // sign bit = rejected
-        rejectedBits = __builtin_amdgcn_alignbit(rejectedBits, rej, 31);  // (bits << 1) | (rej >> 31)
+        // One sign test for both conditions: rejected <=> t > b~ min(b~, bthr).  For b~ <= bthr that is F = b~^2 - t < 0;
+        // for b~ > bthr (centre behind the origin) it is t > b~ bthr, a hair weaker than "origin outside the inflated bound"
+        // (t >= 0; bthr ~ 1e-3, so only origins grazing the bound from outside are kept) and implies it: the candidate set
+        // only grows, the filter stays conservative.  Three VALU operations per (ray, group) pair: min, fma, alignbit.
+        const float g = __builtin_fmaf(min_with_positive(Tb[e], bthr), Tb[e], -t);
+        rejectedBits = __builtin_amdgcn_alignbit(rejectedBits, __float_as_uint(g), 31);  // (bits << 1) | sign(g)
     }
 }
 
 // The filter formula on the VALU (any rounding; the bounds' margins cover it): sign bit set = the bound (C, W) cannot
-// contain an acceptable root of the ray.  dO = d.o, m2a = -2a, cr = a|o|^2 (1 - 2 K eps), bt = the "behind" threshold.
-RT_DEV int bound_rejected(const float4 B, V3 o, V3 d, float a, float dO, float m2a, float cr, float bt) {
-    const float dC = __builtin_fmaf(d.z, B.z, __builtin_fmaf(d.y, B.y, d.x * B.x));
-    const float oC = __builtin_fmaf(o.z, B.z, __builtin_fmaf(o.y, B.y, o.x * B.x));
-    const float b = dO - dC;
-    const float t = cr + __builtin_fmaf(m2a, oC, a * B.w);
-    const float f = __builtin_fmaf(b, b, -t);
-    const float u = bt - b;
-    return __float_as_int(f) | (__float_as_int(u) & ~__float_as_int(t));
+// contain an acceptable root of the ray.  g = -2a o (per ray, rounded once per component: <= 2 eps a |o||C| more rounding
+// than the un-scaled form, inside every K), dO = d.o, cr = a|o|^2 (1 - 2 K eps), bt = the "behind" threshold.
+// b = d.o - d.C and t = a (|C|^2 - Rf^2) - 2a o.C + cr are two fused chains of three and four operations; with the
+// min / fma decision of mfma_post that is nine VALU operations per bound.
+RT_DEV int bound_rejected(const float4 B, V3 g, V3 d, float a, float dO, float cr, float bt) {
+    const float b = __builtin_fmaf(-d.z, B.z, __builtin_fmaf(-d.y, B.y, __builtin_fmaf(-d.x, B.x, dO)));
+    const float t = __builtin_fmaf(g.z, B.z, __builtin_fmaf(g.y, B.y, __builtin_fmaf(g.x, B.x, __builtin_fmaf(a, B.w, cr))));
+    return __float_as_int(__builtin_fmaf(min_with_positive(b, bt), b, -t));  // as mfma_post: rejected <=> t > b min(b, bt)
 }
 
 // Cross-lane hand-off through LDS inside ONE wave (work lists, closest-hit keys, the prepared-path cache): one set of
@@ -500,21 +508,27 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                 const bool has = k < total;
                 const uint32_t item = has ? (uint32_t)poolA[k] : 0u;
                 const uint32_t r = item >> 7, gid = item & 127u;
-                const V3 fo = v3(lane_fetch(r, o.x), lane_fetch(r, o.y), lane_fetch(r, o.z));
+                const V3 fg = v3(lane_fetch(r, gx), lane_fetch(r, gy), lane_fetch(r, gz));
                 const V3 fd = v3(lane_fetch(r, d.x), lane_fetch(r, d.y), lane_fetch(r, d.z));
                 const float fa = lane_fetch(r, a), fdO = lane_fetch(r, dO), fcr = lane_fetch(r, crLeaf), fbt = lane_fetch(r, bt);
                 const float4* lb = leaf + 4u * gid;
                 uint32_t rb = 0u;
 #pragma unroll
                 for (uint32_t q = 0; q < 4; ++q)
-                    rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(lb[q], fo, fd, fa, fdO, -2.f * fa, fcr, fbt), 31);
+                    rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(lb[q], fg, fd, fa, fdO, fcr, fbt), 31);
                 const uint32_t m = has ? (~rb & 15u) : 0u;  // bit 3-q = sphere q of the group
-#pragma unroll
-                for (uint32_t q = 0; q < 4; ++q) {
-                    const bool hit = ((m >> (3u - q)) & 1u) != 0u;
-                    const uint64_t hm = __ballot(hit);
-                    if (hit) poolB[cntB + prefix_count(hm)] = (uint16_t)(r << 10 | (4u * gid + q));
-                    cntB += (uint32_t)__popcll(hm);
+                {   // one prefix sum over the lanes' survivor counts, then every lane appends its own (0..4) entries
+                    const uint32_t nh = (uint32_t)__builtin_popcount(m);
+                    const uint32_t incl = wave_inclusive_sum(nh);
+                    const uint32_t totalH = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    uint16_t* wp = poolB + cntB + (incl - nh);
+                    uint32_t mm = m;
+                    while (mm != 0u) {
+                        const uint32_t bit = 31u - (uint32_t)__builtin_clz(mm);
+                        mm &= ~(1u << bit);
+                        *wp++ = (uint16_t)(r << 10 | (4u * gid + (3u - bit)));
+                    }
+                    cntB += totalH;
                 }
                 if (cntB > kPoolB - 4u * kWaveSize) drainB();
             }
@@ -596,7 +610,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
             nWork -= np;
             wave_lds_handoff();  // popped slots are free for this round's pushes
             const uint32_t r = ent >> 20, lvl = (ent >> 16) & 7u, j = ent & 0xffffu;
-            const V3 fo = v3(lane_fetch(r, o.x), lane_fetch(r, o.y), lane_fetch(r, o.z));
+            const V3 fg = v3(lane_fetch(r, gx), lane_fetch(r, gy), lane_fetch(r, gz));
             const V3 fd = v3(lane_fetch(r, d.x), lane_fetch(r, d.y), lane_fetch(r, d.z));
             const float fa = lane_fetch(r, a), fdO = lane_fetch(r, dO), faoo = lane_fetch(r, aoo), fbt = lane_fetch(r, bt);
             const bool internal = lvl > 0u;
@@ -613,12 +627,11 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                 B0 = lb[0]; B1 = lb[1]; B2 = lb[2]; B3 = lb[3];
             }
             const float fcr = faoo * (internal ? (1.f - 2.f * kMarginKValu * 5.9604645e-8f) : (1.f - 2.f * kMarginKLeaf * 5.9604645e-8f));
-            const float fm2a = -2.f * fa;
             uint32_t rb = 0u;
-            rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B0, fo, fd, fa, fdO, fm2a, fcr, fbt), 31);
-            rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B1, fo, fd, fa, fdO, fm2a, fcr, fbt), 31);
-            rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B2, fo, fd, fa, fdO, fm2a, fcr, fbt), 31);
-            rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B3, fo, fd, fa, fdO, fm2a, fcr, fbt), 31);
+            rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B0, fg, fd, fa, fdO, fcr, fbt), 31);
+            rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B1, fg, fd, fa, fdO, fcr, fbt), 31);
+            rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B2, fg, fd, fa, fdO, fcr, fbt), 31);
+            rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B3, fg, fd, fa, fdO, fcr, fbt), 31);
             const uint32_t m = has ? (~rb & 15u) : 0u;  // bit 3-q = child 4j + q
             if (nExact > kTreeExact - 4u * kWaveSize) drainExact();
 #pragma unroll

@@ -55,7 +55,7 @@ struct ScriptedDraws {
 // Emit + Shade with the sun visible and localOccluded = Emit + 0 (the caller adds one of the two once the
 // shadow scan has decided; Emit is non-zero only for Emissive spheres, which never scatter).
 template <class Draws>
-RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V3& outDir, V3& tex) {
+RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V3& outDir, V3& tex, const MathTabs& mt = default_math_tabs()) {
     const float uvx = 0.5f * nrm.x + 0.5f;  // Sphere::ComputeUV, ray-tracing.cpp:26-40
     const float uvy = 0.5f * nrm.z + 0.5f;
     tex = eval_texture(m, uvx, uvy);
@@ -111,7 +111,7 @@ RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V
                 const float r = __builtin_sqrtf(1.f - u1 * u1);  // quasi-random.cpp:41
                 const float phi = (2.f * 3.141592654f) * u2;
                 double sn, cs;
-                sincos_f64(phi, sn, cs);
+                sincos_f64(phi, sn, cs, mt);
                 const float hx = r * (float)cs, hy = r * (float)sn, hz = u1;
                 const V3 b3 = nrm;
                 const V3 up = __builtin_fabsf(nrm.x) < 0.5f ? v3(1.f, 0.f, 0.f) : v3(0.f, 1.f, 0.f);
@@ -129,7 +129,8 @@ RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V
 
 // Emit + DirectionalLight::Shade's unoccluded value (light.cpp:21-40) and Emit + 0 (its value when occluded).
 template <class P>
-RT_DEV void shade_value(const P& p, const Mat& m, V3 tex, V3 pos, V3 nrm, bool wantShade, V3& local, V3& localOccluded) {
+RT_DEV void shade_value(const P& p, const Mat& m, V3 tex, V3 pos, V3 nrm, bool wantShade, V3& local, V3& localOccluded,
+                        const MathTabs& mt = default_math_tabs()) {
     V3 emit = v3(0.f, 0.f, 0.f);
     if (m.type == RT_MAT_EMISSIVE) emit = m.luminance * tex;  // material.cpp:172-175; 0 for every other material
     localOccluded = emit + v3(0.f, 0.f, 0.f);  // Shade returns XM_Zero when the sun is occluded (light.cpp:15-18)
@@ -151,7 +152,7 @@ RT_DEV void shade_value(const P& p, const Mat& m, V3 tex, V3 pos, V3 nrm, bool w
     const float nDotH = sat1(dot3(nrm, halfVector));
     const float nDotV2 = sat1(dot3(viewDir, nrm));
     const float p5 = rt_powf(1.f - nDotV2, 5.f);
-    const float ps = rt_powf(nDotH, smooth);
+    const float ps = rt_powf(nDotH, smooth, mt);
     const V3 one = v3(1.f, 1.f, 1.f);
     const V3 reflectance = f0 + (one - f0) * p5;
     const V3 spec = ((reflectance * 0.125f) * (smooth + 8.f)) * ps;
