@@ -11,7 +11,8 @@
 
 static void Usage() {
     std::puts("usage: spheres [--width N] [--height N] [--spp N] [--frame-spp N] [--depth N] [--fov F] [--aperture F]\n"
-              "               [--scene cover|three|grid10k] [--scene-seed N] [--seed N] [--device N] [--gpus N] [--out file.ppm] [--quiet]");
+              "               [--scene cover|three|grid10k] [--scene-seed N] [--seed N] [--device N] [--gpus N] [--out file.ppm] [--quiet]\n"
+              "               [--sampler reference|cosine|sqrtdisk|cosine+sqrtdisk]   (default: the reference's mappings)");
 }
 
 int main(int argc, char** argv) {
@@ -40,6 +41,12 @@ int main(int argc, char** argv) {
         else if (k == "--gpus") gpus = std::atoi(val());
         else if (k == "--out") out = val();
         else if (k == "--quiet") quiet = true;
+        else if (k == "--sampler") {
+            const std::string v = val();
+            st.samplerFlags = (v.find("cosine") != std::string::npos ? RT_SAMPLER_COSINE_HEMISPHERE : 0u) |
+                              (v.find("sqrtdisk") != std::string::npos ? RT_SAMPLER_SQRT_DISK : 0u);
+            if (st.samplerFlags == 0u && v != "reference") { Usage(); return 2; }
+        }
         else { Usage(); return k == "--help" ? 0 : 2; }
     }
     if (st.scene == "three") {  // C1 defaults

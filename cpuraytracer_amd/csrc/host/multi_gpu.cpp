@@ -86,7 +86,8 @@ int RenderMultiGpu(const AppSettingsT& st, int nGpus, uint32_t spp, MultiGpuResu
             HIP_OK(hipMemset(rk.hdrStrip, 0, stripPix * 3 * sizeof(float)));
             HIP_OK(hipMemset(rk.ldrStrip, 0, stripPix * 3));
             if (rt_create(rk.device, &rk.ctx) != RT_OK || rt_set_stream(rk.ctx, rk.stream) != RT_OK ||
-                rt_scene_upload(rk.ctx, spheres.data(), materials.data(), (uint32_t)spheres.size(), &camera, &sun, &sky, exposure) != RT_OK)
+                rt_scene_upload(rk.ctx, spheres.data(), materials.data(), (uint32_t)spheres.size(), &camera, &sun, &sky, exposure) != RT_OK ||
+                rt_set_sampler(rk.ctx, st.samplerFlags) != RT_OK)
                 rk.error = rt_last_error();
         }();
         if (!rk.error.empty()) return fail("device " + std::to_string(r) + ": " + rk.error);

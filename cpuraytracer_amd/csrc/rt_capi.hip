@@ -89,6 +89,7 @@ struct rt_ctx {
     uint32_t W = 0, H = 0, rows = 0;
     rt_rowset rs{};
     uint32_t accumulated = 0;  // samples accumulated so far (next s0 must be accumulated + 1)
+    uint32_t sampler = 0;      // RT_SAMPLER_* flags of the next / running accumulation (rt_set_sampler)
     DevBuf<float> hdr;         // [W*rows*3]
     DevBuf<uint8_t> ldr;       // [W*rows*3]
     DevBuf<float> samples;     // workspace [pixels*spp_pass*3]
@@ -812,6 +813,13 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     return RT_OK;
 }
 
+int rt_set_sampler(rt_ctx* ctx, uint32_t flags) {
+    if (!ctx || (flags & ~(RT_SAMPLER_COSINE_HEMISPHERE | RT_SAMPLER_SQRT_DISK)) != 0u) return Fail(RT_ERR_INVALID_ARG, "rt_set_sampler: unknown flag");
+    if (flags != ctx->sampler) ctx->accumulated = 0;  // samples of two mappings do not mix: the next rt_render starts over
+    ctx->sampler = flags;
+    return RT_OK;
+}
+
 int rt_clear(rt_ctx* ctx) {
     if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_clear: null ctx");
     ctx->accumulated = 0;
@@ -882,6 +890,7 @@ int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, ui
             tp.total_paths = npix * spp;
             tp.npix_local = npix;
             tp.max_depth = max_depth;
+            tp.sampler = ctx->sampler;
             tp.seed = seed;
             tp.path_list = nullptr;
             tp.samples = ctx->samples.ptr;
@@ -906,7 +915,7 @@ int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, ui
             {
                 const uint32_t nmax = spp > nLens ? spp : nLens;
                 hipLaunchKernelGGL(rtd::rt_raygen_tables_kernel, dim3((nmax + 255) / 256), dim3(256), 0, ctx->stream, ctx->jitterTab.ptr, s,
-                                   spp, ctx->lensTab.ptr, k0, nLens);
+                                   spp, ctx->lensTab.ptr, k0, nLens, ctx->sampler);
                 RT_HIP(hipGetLastError());
             }
             if ((rc = LaunchTrace(ctx, tp)) != RT_OK) return rc;
@@ -1048,6 +1057,7 @@ int rt_unit_primary_rays(rt_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* ij
     rtd::TraceParams tp = ctx->base;
     tp.W = W;
     tp.H = H;
+    tp.sampler = ctx->sampler;
     hipLaunchKernelGGL(rtd::k_unit_primary, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, tp, dIjs.p, n, dOut.p);
     RT_HIP(hipGetLastError());
     RT_HIP(hipStreamSynchronize(ctx->stream));
@@ -1122,6 +1132,7 @@ int rt_unit_trace(rt_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* ijs, uint
     tp.total_paths = n;
     tp.npix_local = n;
     tp.max_depth = max_depth;
+    tp.sampler = ctx->sampler;
     tp.seed = seed;
     tp.path_list = dIjs.p;
     tp.jitter_tab = nullptr;
@@ -1180,6 +1191,7 @@ int rt_unit_scatter(rt_ctx* ctx, const rt_material* material, const rt_light* su
         tp.sun_dir[k] = sun->direction[k];
         tp.sun_rad[k] = sun->luminance * sun->color[k];
     }
+    tp.sampler = ctx->sampler;
     hipLaunchKernelGGL(rtd::k_unit_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, tp, dMat.p, dIn.p, n, dOut.p);
     RT_HIP(hipGetLastError());
     RT_HIP(hipStreamSynchronize(ctx->stream));

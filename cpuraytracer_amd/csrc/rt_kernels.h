@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                 const V3 nrm = (pos - center) / radius;  // ray-tracing.cpp:58
                 V3 atten, local, localOcc, tex;
                 RT_STAMP(th0);
-                const bool scattered = scatter_only(m, rd, nrm, draws, atten, nextDir, tex, mt);  // Scatter first: it draws (spheres-app.cpp:246)
+                const bool scattered = scatter_only(m, rd, nrm, draws, atten, nextDir, tex, mt, K.sampler);  // Scatter first: it draws (spheres-app.cpp:246)
                 RT_STAMP(th1);
                 const bool cont = (depth < p.max_depth) && scattered;  // spheres-app.cpp:247
                 const bool useIndex = K.sg_enabled && dot3(pos, pos) <= K.sg_p0sq;
@@ -504,12 +504,12 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
 // ============================================================ ray-generation tables (A1, A9)
 // jitter[k] = Halton2D(s0+k; 2,3) (spheres-app.cpp:140), lens[k] = HaltonSampleDisk(k0+k; 4,5) (:152)
 __global__ void __launch_bounds__(256) rt_raygen_tables_kernel(float2* jitter, uint32_t s0, uint32_t nJitter, float2* lens, uint32_t k0,
-                                                               uint32_t nLens) {
+                                                               uint32_t nLens, uint32_t sampler) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < nJitter) jitter[k] = make_float2(halton(s0 + k, 2), halton(s0 + k, 3));
     if (k < nLens) {
         float lx, ly;
-        halton_disk_4_5(k0 + k, lx, ly);
+        halton_disk_4_5(k0 + k, lx, ly, sampler);
         lens[k] = make_float2(lx, ly);
     }
 }
@@ -657,7 +657,7 @@ __global__ void k_unit_scatter(const TraceParams p, const rt_material* mat, cons
     const Mat m = load_material(mat, 0);
     ScriptedDraws draws{{q[9], q[10], q[11]}, 0u};
     V3 atten, dir, local, localOcc;
-    const bool sc = scatter_and_shade(p, m, v3(q[0], q[1], q[2]), v3(q[3], q[4], q[5]), v3(q[6], q[7], q[8]), draws, atten, dir, local, localOcc);
+    const bool sc = scatter_and_shade(p, m, v3(q[0], q[1], q[2]), v3(q[3], q[4], q[5]), v3(q[6], q[7], q[8]), draws, atten, dir, local, localOcc, p.sampler);
     float* w = out + 11 * (size_t)k;
     w[0] = sc ? 1.f : 0.f;
     w[1] = atten.x; w[2] = atten.y; w[3] = atten.z;

@@ -75,6 +75,7 @@ struct TraceParams {
     uint32_t total_paths; // W * local_rows * spp_pass, or the path-list length
     uint32_t npix_local;  // W * local_rows (the sample buffer is [sample of the pass][local pixel])
     uint32_t max_depth;
+    uint32_t sampler;     // RT_SAMPLER_* flags (rt_api.h): 0 = the reference's mappings
     uint64_t seed;
     const uint32_t* path_list;  // optional explicit (i, j, s) triples (unit tests)
     const float2* jitter_tab;   // [spp_pass] Halton2D(s;2,3) for s = s0.. (rt_raygen_tables_kernel), or null
@@ -100,6 +101,7 @@ struct SceneConsts {
     float sg_e1[3], sg_e2[3], sg_u0, sg_v0, sg_inv_cell, sg_p0sq;
     uint32_t sg_nx, sg_ny, sg_nglobal, sg_enabled;
     uint32_t W, H, s0, lens_k0;
+    uint32_t sampler;
     const float2* jitter_tab;
     const float2* lens_tab;
 };
@@ -116,7 +118,7 @@ RT_DEV void fill_consts(const TraceParams& p, SceneConsts& k) {
     k.aperture = p.aperture; k.focal = p.focal; k.exposure = p.exposure;
     k.sg_u0 = p.sg_u0; k.sg_v0 = p.sg_v0; k.sg_inv_cell = p.sg_inv_cell; k.sg_p0sq = p.sg_p0sq;
     k.sg_nx = p.sg_nx; k.sg_ny = p.sg_ny; k.sg_nglobal = p.sg_nglobal; k.sg_enabled = p.sg_enabled;
-    k.W = p.W; k.H = p.H; k.s0 = p.s0; k.lens_k0 = p.lens_k0;
+    k.W = p.W; k.H = p.H; k.s0 = p.s0; k.lens_k0 = p.lens_k0; k.sampler = p.sampler;
     k.jitter_tab = p.jitter_tab; k.lens_tab = p.lens_tab;
 }
 
@@ -147,9 +149,10 @@ RT_DEV void camera_get_ray(const P& p, float uvx, float uvy, float lensx, float 
 // ------------------------------------------------------------------ primary rays (A1, A2)
 // SpheresApp::GenerateRays (spheres-app.cpp:132-161) + Camera::GetRay (camera.cpp:30-48) for one
 // (i, j, s).  jitter = Halton2D(s;2,3); lens = HaltonSampleDisk(s+i+j;4,5).
-RT_DEV void halton_disk_4_5(uint32_t k, float& lensx, float& lensy) {  // quasi-random.cpp:52-61
+RT_DEV void halton_disk_4_5(uint32_t k, float& lensx, float& lensy, uint32_t sampler = 0u) {  // quasi-random.cpp:52-61
     const float theta = (2.f * 3.141592654f) * halton(k, 4);
-    const float r = halton(k, 5);
+    float r = halton(k, 5);  // the reference does not take the square root: a centre-weighted disk
+    if (sampler & RT_SAMPLER_SQRT_DISK) r = __builtin_sqrtf(r);
     double sn, cs;
     sincos_f64(theta, sn, cs);
     lensx = r * (float)cs;
@@ -173,7 +176,7 @@ RT_DEV void gen_primary_ray(const P& p, uint32_t i, uint32_t j, uint32_t s, V3& 
     } else {
         jx = halton(s, 2);
         jy = halton(s, 3);
-        halton_disk_4_5(li, lensx, lensy);
+        halton_disk_4_5(li, lensx, lensy, p.sampler);
     }
     const float uvx = ((float)(int)i + jx) / xsize;
     const float uvy = ((float)(int)j + jy) / ysize;

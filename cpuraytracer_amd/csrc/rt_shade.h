@@ -55,7 +55,8 @@ struct ScriptedDraws {
 // Emit + Shade with the sun visible and localOccluded = Emit + 0 (the caller adds one of the two once the
 // shadow scan has decided; Emit is non-zero only for Emissive spheres, which never scatter).
 template <class Draws>
-RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V3& outDir, V3& tex, const MathTabs& mt = default_math_tabs()) {
+RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V3& outDir, V3& tex, const MathTabs& mt = default_math_tabs(),
+                         uint32_t sampler = 0u) {
     const float uvx = 0.5f * nrm.x + 0.5f;  // Sphere::ComputeUV, ray-tracing.cpp:26-40
     const float uvy = 0.5f * nrm.z + 0.5f;
     tex = eval_texture(m, uvx, uvy);
@@ -108,11 +109,13 @@ RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V
                 atten = tex;
                 const float u1 = draws.next();  // HaltonSampleHemisphere's two dimensions
                 const float u2 = draws.next();
-                const float r = __builtin_sqrtf(1.f - u1 * u1);  // quasi-random.cpp:41
+                // quasi-random.cpp:41: uniform in solid angle (z = u1); the flagged variant is cosine weighted
+                const bool cosine = (sampler & RT_SAMPLER_COSINE_HEMISPHERE) != 0u;
+                const float r = __builtin_sqrtf(cosine ? u1 : 1.f - u1 * u1);
                 const float phi = (2.f * 3.141592654f) * u2;
                 double sn, cs;
                 sincos_f64(phi, sn, cs, mt);
-                const float hx = r * (float)cs, hy = r * (float)sn, hz = u1;
+                const float hx = r * (float)cs, hy = r * (float)sn, hz = cosine ? __builtin_sqrtf(1.f - u1) : u1;
                 const V3 b3 = nrm;
                 const V3 up = __builtin_fabsf(nrm.x) < 0.5f ? v3(1.f, 0.f, 0.f) : v3(0.f, 1.f, 0.f);
                 const V3 b1 = cross3(up, b3);
@@ -163,9 +166,9 @@ RT_DEV void shade_value(const P& p, const Mat& m, V3 tex, V3 pos, V3 nrm, bool w
 // Scatter, then Emit + Shade with the sun assumed visible (the scan-based shadow path decides later).
 template <class P, class Draws>
 RT_DEV bool scatter_and_shade(const P& p, const Mat& m, V3 rd, V3 pos, V3 nrm, Draws& draws, V3& atten, V3& outDir,
-                              V3& local, V3& localOccluded) {
+                              V3& local, V3& localOccluded, uint32_t sampler = 0u) {
     V3 tex;
-    const bool scattered = scatter_only(m, rd, nrm, draws, atten, outDir, tex);
+    const bool scattered = scatter_only(m, rd, nrm, draws, atten, outDir, tex, default_math_tabs(), sampler);
     shade_value(p, m, tex, pos, nrm, true, local, localOccluded);
     return scattered;
 }

@@ -37,6 +37,10 @@ class HipRenderer:
     def set_workspace_limit(self, nbytes):
         check(self._L.rt_set_workspace_limit(self._h, int(nbytes)))
 
+    def set_sampler(self, flags):
+        """RT_SAMPLER_* flags (0 = the reference's uniform hemisphere and linear-r disk)."""
+        check(self._L.rt_set_sampler(self._h, int(flags)))
+
     def upload(self, scene):
         """scene: object with .spheres/.materials (numpy structured arrays in the rt_api.h layouts), .camera, .sun,
         .sky (ctypes structs of identical layout), .exposure_scale."""

@@ -162,6 +162,17 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
 int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1,
               uint32_t max_depth, uint64_t seed, rt_stats* out_stats);
 
+/* Sampler variants.  Default 0 = the reference's own mappings: HaltonSampleHemisphere is uniform
+ * in solid angle (quasi-random.cpp:36-50: z = u1, r = sqrt(1 - u1^2); NOT cosine weighted, and the caller applies
+ * no pdf) and HaltonSampleDisk takes r = u (quasi-random.cpp:52-61: NOT sqrt'ed, centre-weighted lens).  The flags
+ * select the textbook mappings instead, with the same draws in the same order:
+ *   RT_SAMPLER_COSINE_HEMISPHERE  r = sqrt(u1), z = sqrt(1 - u1), phi = 2 pi u2   (DielectricOpaque diffuse bounce)
+ *   RT_SAMPLER_SQRT_DISK          r = sqrt(u)                                     (lens offsets, GenerateRays :152)
+ * Takes effect at the next accumulation (rt_render with s0 == 1); changing it voids a running one. */
+#define RT_SAMPLER_COSINE_HEMISPHERE 1u
+#define RT_SAMPLER_SQRT_DISK 2u
+int rt_set_sampler(rt_ctx* ctx, uint32_t flags);
+
 /* Forget the accumulated HDR strip and sample count. */
 int rt_clear(rt_ctx* ctx);
 
@@ -211,7 +222,7 @@ int rt_unit_camera_rays(rt_ctx* ctx, const rt_camera* camera, const float* uv_of
  * material record.  in: ray direction 3, hit pos 3, hit normal 3, three uniforms consumed in call order (12 floats);
  * out: scattered flag, attenuation 3, scattered direction 3, draws consumed, Emit+Shade 3 (11 floats). */
 int rt_unit_scatter(rt_ctx* ctx, const rt_material* material, const rt_light* sun, const float view_origin[3],
-                    const float* in, uint32_t n, float* out);
+                    const float* in, uint32_t n, float* out);  /* uses the context's sampler flags */
 /* Host-only view of the clustered storage rt_scene_upload builds for the scan (groups of four spheres with a
  * conservative bounding sphere each).  orig: 4 entries per group, 0xffffffff = padding;
  * bounds: Cx, Cy, Cz, |C|^2 - Rf^2 per group.  cap_groups == 0 only queries *n_groups.  Needs no GPU. */

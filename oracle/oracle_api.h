@@ -30,6 +30,8 @@ int orc_render(orc_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, 
                uint64_t seed, int accel, int threads, rt_stats* out_stats);
 /* N3: drive material draws from the reference's per-material Halton counters (serial renders only) */
 void orc_use_reference_halton_counters(int on);
+/* N3: sampler variants behind flags (RT_SAMPLER_*, include/rt_api.h); process-wide, 0 = the reference's mappings */
+void orc_set_sampler(uint32_t flags);
 int orc_clear(orc_ctx* ctx);
 int orc_resolve(orc_ctx* ctx, uint32_t n_samples);
 int orc_download(orc_ctx* ctx, float* hdr_rgb, uint8_t* ldr_rgb);

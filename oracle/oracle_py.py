@@ -106,6 +106,8 @@ def lib():
         L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, RtRowset, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.c_uint64, C.c_int, C.c_int, C.POINTER(RtStats)]
         L.orc_use_reference_halton_counters.argtypes = [C.c_int]
+        L.orc_set_sampler.argtypes = [C.c_uint32]
+        L.orc_set_sampler.restype = None
         L.orc_clear.argtypes = [C.c_void_p]
         L.orc_resolve.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

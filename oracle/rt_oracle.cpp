@@ -36,11 +36,18 @@ XMFLOAT2 HaltonSampleRing(uint64_t sampleIndex, uint32_t base) {
     return XMFLOAT2(rt_cosf(theta), rt_sinf(theta));
 }
 
+// Sampler variants behind flags (include/rt_api.h RT_SAMPLER_*): 0 = the reference's mappings.
+static uint32_t g_samplerFlags = 0;
+void SetSamplerFlags(uint32_t flags) { g_samplerFlags = flags; }
+uint32_t SamplerFlags() { return g_samplerFlags; }
+
 // quasi-random.cpp:36-50 body, on two given uniforms: uniform in solid angle (NOT cosine weighted).
+// Flag RT_SAMPLER_COSINE_HEMISPHERE: the textbook cosine-weighted mapping r = sqrt(u1), z = sqrt(1 - u1).
 XMFLOAT3 HemisphereFromUniforms(float u1, float u2) {
-    const float r = std::sqrt(1.f - u1 * u1);
+    const bool cosine = (g_samplerFlags & RT_SAMPLER_COSINE_HEMISPHERE) != 0u;
+    const float r = std::sqrt(cosine ? u1 : 1.f - u1 * u1);
     const float phi = 2 * XM_PI * u2;
-    return XMFLOAT3(r * rt_cosf(phi), r * rt_sinf(phi), u1);
+    return XMFLOAT3(r * rt_cosf(phi), r * rt_sinf(phi), cosine ? std::sqrt(1.f - u1) : u1);
 }
 
 // quasi-random.cpp:36-50
@@ -50,10 +57,11 @@ XMFLOAT3 HaltonSampleHemisphere(uint64_t sampleIndex, uint32_t base1, uint32_t b
     return HemisphereFromUniforms(u1, u2);
 }
 
-// quasi-random.cpp:52-61 — r is NOT sqrt'ed (centre-weighted disk).
+// quasi-random.cpp:52-61 — r is NOT sqrt'ed (centre-weighted disk).  Flag RT_SAMPLER_SQRT_DISK: r = sqrt(u), uniform in area.
 XMFLOAT2 HaltonSampleDisk(uint64_t sampleIndex, uint32_t base1, uint32_t base2) {
     float theta = 2.f * XM_PI * HaltonSample(sampleIndex, base1);
     float r = HaltonSample(sampleIndex, base2);
+    if (g_samplerFlags & RT_SAMPLER_SQRT_DISK) r = std::sqrt(r);
     return XMFLOAT2(r * rt_cosf(theta), r * rt_sinf(theta));
 }
 

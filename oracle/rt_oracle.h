@@ -80,6 +80,8 @@ float NextMaterialDraw();
 // HaltonSample(counter++, base) on the material's own counter exactly as material.cpp:29,44,82,151 do —
 // only meaningful for a SERIAL render (the reference's counters are racy under its thread pool).  Used by the
 // statistical parity test; the deterministic per-path stream stays the contract for the GPU parity tests.
+void SetSamplerFlags(uint32_t flags);  // RT_SAMPLER_* (include/rt_api.h); 0 = the reference's mappings
+uint32_t SamplerFlags();
 void UseReferenceHaltonCounters(bool on);
 bool ReferenceHaltonCounters();
 float Draw(uint64_t& counter, uint32_t base);                                      // one uniform

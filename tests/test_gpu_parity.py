@@ -573,6 +573,118 @@ def test_c4_full_size_depth_of_field(hip, oracle, scenes_mod):
         assert list(out) == list(ldr[j, i])
 
 
+# ------------------------------------------------------------------- sampler variants
+@pytest.mark.parametrize("flags", [1, 2, 3], ids=["cosine-hemisphere", "sqrt-disk", "cosine+sqrt-disk"])
+def test_sampler_variants_device_vs_oracle(hip, oracle, scenes_mod, flags):
+    """rt_set_sampler: cosine-weighted hemisphere and area-uniform lens disk behind flags, bit-exact against the oracle's
+    same flags at three levels: lens offsets / primary rays (aperture 2.0), DielectricOpaque::Scatter on scripted draws,
+    and a cover-scene image with its traversal counters.  The image must differ from the reference-mapping image."""
+    from cpuraytracer_amd import _capi
+    W, H = 96, 64
+    sc = scenes_mod.build_scene("cover", 1, W, H, aperture=2.0)
+    hip.upload(sc)
+    hip.set_sampler(0)
+    hip.render(W, H, 1, 4, 50, 1)
+    base = hip.download(ldr=False)[0]
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    try:
+        hip.set_sampler(flags)
+        oracle.lib().orc_set_sampler(flags)
+        # (a) primary rays
+        rng = np.random.default_rng(21)
+        ijs = np.stack([rng.integers(0, W, 4000), rng.integers(0, H, 4000), rng.integers(1, 600, 4000)], 1).astype(np.uint32)
+        assert_same(hip.unit_primary_rays(W, H, ijs), orc.primary_rays(W, H, ijs), "primary rays, sampler %d" % flags)
+        # (b) opaque scatter on scripted draws (the diffuse branch consumes u1, u2)
+        k255 = np.float32(1.0) / np.float32(255.0)
+        sun = oracle.RtLight()
+        for k in range(3):
+            sun.direction[k] = float(np.float32(1.0) / np.sqrt(np.float32(3.0)))
+            sun.color[k] = 1.0
+        sun.luminance = 40000.0
+        view = (C.c_float * 3)(12.0, 2.0, -2.5)
+        m = oracle.RtMaterial()
+        m.type, m.tex_type, m.smoothness, m.ior, m.tiling, m.luminance = 0, 0, 35.5, 1.5, 1.0, 0.0
+        for k in range(3):
+            m.rgb0[k] = float(np.float32((230, 128, 26)[k]) * k255)
+        n = 2000
+        nrm = rng.normal(size=(n, 3))
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        rd = -nrm + 0.3 * rng.normal(size=(n, 3))  # front facing
+        rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+        draws = rng.uniform(0, 1, size=(n, 3))
+        draws[:, 0] = 0.9 + 0.1 * draws[:, 0]  # the coin falls on the diffuse side
+        inp = np.concatenate([rd, rng.uniform(-5, 5, size=(n, 3)), nrm, draws], 1).astype(np.float32)
+        out = np.zeros((n, 11), dtype=np.float32)
+        mm = _capi.RtMaterial.from_buffer_copy(bytes(m))
+        ss = _capi.RtLight.from_buffer_copy(bytes(sun))
+        _capi.check(hip._L.rt_unit_scatter(hip._h, C.byref(mm), C.byref(ss), view, inp.ctypes.data, n, out.ctypes.data))
+        f = lambda a: (C.c_float * len(a))(*[float(v) for v in a])
+        want_dir = np.zeros((n, 3), dtype=np.float32)
+        front = np.einsum("ij,ij->i", inp[:, 0:3].astype(np.float64), inp[:, 6:9].astype(np.float64)) < -0.05
+        assert front.mean() > 0.95
+        for i in np.flatnonzero(front):
+            uv = (C.c_float * 2)(float(np.float32(0.5) * inp[i, 6] + np.float32(0.5)), float(np.float32(0.5) * inp[i, 8] + np.float32(0.5)))
+            att, dr, nd = (C.c_float * 3)(), (C.c_float * 3)(), C.c_uint32()
+            scd = oracle.lib().orc_unit_scatter(C.byref(m), f(inp[i, 0:3]), f(inp[i, 3:6]), f(inp[i, 6:9]), uv, f(inp[i, 9:12]), att, dr,
+                                                C.byref(nd))
+            assert scd == 1 and nd.value == 3 and out[i, 0] == 1.0 and out[i, 7] == 3.0
+            want_dir[i] = list(dr)
+        assert_same(out[front, 4:7], want_dir[front], "diffuse directions, sampler %d" % flags)
+        # (c) image
+        sg = hip.render(W, H, 1, 4, 50, 1)
+        hip.resolve()
+        hg, lg = hip.download()
+        so = orc.render(W, H, 1, 4, 50, 1, accel=oracle.ACCEL_BVH, threads=8)
+        orc.resolve()
+        ho, lo = orc.download()
+        assert_same(hg, ho, "HDR, sampler %d" % flags)
+        assert_same(lg, lo, "LDR, sampler %d" % flags)
+        assert (sg.traversals, sg.segments) == (so.traversals, so.segments)
+        assert not np.array_equal(hg, base)
+        # a running accumulation cannot switch mappings
+        from cpuraytracer_amd import RtError
+        hip.set_sampler(0)
+        with pytest.raises(RtError) as e:
+            hip.render(W, H, 4, 5, 50, 1)
+        assert e.value.code == 6  # RT_ERR_SEQUENCE
+    finally:
+        hip.set_sampler(0)
+        oracle.lib().orc_set_sampler(0)
+    with pytest.raises(Exception):
+        hip.set_sampler(8)
+
+
+def test_gpu_image_agrees_with_the_reference_halton_counter_estimator(hip, oracle, scenes_mod):
+    """SURVEY.md §8f N3 on the GPU side: the HIP render (per-path xoshiro streams) against the oracle driven by the
+    reference's own per-material global Halton counters (material.h:34,50-51,67; serial, so reproducible).  Per-pixel
+    parity with the original binary is impossible; the two are the same estimator, so the converged
+    images agree within Monte-Carlo error, measured by two HIP renders with different seeds."""
+    W, H, spp = 96, 64, 256
+    sc = scenes_mod.build_scene("cover", 1, W, H)
+    try:
+        oracle.lib().orc_use_reference_halton_counters(1)
+        orc = oracle.Oracle()
+        orc.upload(sc)  # fresh materials: counters start at 0 like a fresh process
+        orc.render(W, H, 1, 1 + spp, 50, 1, accel=oracle.ACCEL_BVH, threads=1)
+        ref, _ = orc.download()
+    finally:
+        oracle.lib().orc_use_reference_halton_counters(0)
+    hip.upload(sc)
+    imgs = []
+    for seed in (1, 2):
+        hip.render(W, H, 1, 1 + spp, 50, seed)
+        imgs.append(hip.download(ldr=False)[0])
+    a, b = imgs[0] / spp, imgs[1] / spp
+    ref = ref / spp
+    assert np.allclose(ref.mean(axis=(0, 1)), a.mean(axis=(0, 1)), rtol=0.02)
+    noise = np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(2)  # per-pixel std of one estimate
+    rms = np.sqrt(np.mean((ref - a) ** 2))
+    assert rms < 2.0 * noise, (rms, noise)
+    blk = lambda x: x.reshape(8, 8, 12, 8, 3).mean(axis=(1, 3))  # 8x8-block averages: noise / 8
+    assert np.max(np.abs(blk(ref) - blk(a))) < 8.0 * noise / 8.0 + 0.01 * blk(a).max()
+
+
 # ------------------------------------------------ launch/layout knobs: every combination gives the same bits (DESIGN.md §8b)
 def _render_with_env(monkeypatch, env, sc, W, H, s1, depth=50, seed=1):
     """Render on a fresh context created under `env` (the knobs are read at rt_create)."""

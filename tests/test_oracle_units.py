@@ -5,6 +5,7 @@ import ctypes as C
 import json
 import math
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -69,6 +70,44 @@ def test_disk_radius_is_not_sqrt(oracle):
     for i in range(1, 200):
         L.orc_halton_disk(i, 4, 5, o2)
         assert abs(math.hypot(o2[0], o2[1]) - L.orc_halton(i, 5)) < 1e-6
+
+
+def test_flagged_sampler_variants_are_the_textbook_mappings(oracle):
+    """RT_SAMPLER_COSINE_HEMISPHERE and RT_SAMPLER_SQRT_DISK (include/rt_api.h) select the cosine-weighted
+    hemisphere (E[z] = 2/3, z = sqrt(1 - u1)) and the area-uniform disk (r = sqrt(u), E[r] = 2/3) on the same Halton
+    points; flag 0 restores the reference's mappings (E[z] = E[r] = 1/2)."""
+    L = oracle.lib()
+    o3, o2 = (C.c_float * 3)(), (C.c_float * 2)()
+    try:
+        L.orc_set_sampler(3)
+        zs, rs = [], []
+        for i in range(1, 600):
+            L.orc_halton_hemisphere(i, 5, 7, o3)
+            v = np.array(list(o3), dtype=np.float64)
+            u1 = L.orc_halton(i, 5)
+            assert abs(np.linalg.norm(v) - 1.0) < 1e-6 and v[2] >= 0
+            assert f32(v[2]) == np.sqrt(np.float32(1.0) - np.float32(u1))
+            zs.append(v[2])
+            L.orc_halton_disk(i, 4, 5, o2)
+            assert abs(math.hypot(o2[0], o2[1]) - math.sqrt(L.orc_halton(i, 5))) < 1e-6
+            rs.append(math.hypot(o2[0], o2[1]))
+        assert abs(np.mean(zs) - 2 / 3) < 0.02 and abs(np.mean(rs) - 2 / 3) < 0.02
+        L.orc_set_sampler(1)
+        L.orc_halton_disk(7, 4, 5, o2)
+        assert abs(math.hypot(o2[0], o2[1]) - L.orc_halton(7, 5)) < 1e-6  # disk flag off: linear r
+    finally:
+        L.orc_set_sampler(0)
+    L.orc_halton_hemisphere(9, 5, 7, o3)
+    assert f32(o3[2]) == L.orc_halton(9, 5)
+
+
+def test_math_tables_are_the_generated_ones():
+    """oracle/math_tables.inc and cpuraytracer_amd/csrc/rt_math_tables.inc carry the same literal data, equal to what
+    tools/gen_math_tables.py regenerates (double nearest to the exact value, mpmath at 80 digits)."""
+    import subprocess
+    from conftest import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_math_tables.py"), "--check"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
 
 
 # ------------------------------------------------------ elementary-function contract
