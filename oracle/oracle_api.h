@@ -32,6 +32,9 @@ int orc_render(orc_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, 
 void orc_use_reference_halton_counters(int on);
 /* N3: sampler variants behind flags (RT_SAMPLER_*, include/rt_api.h); process-wide, 0 = the reference's mappings */
 void orc_set_sampler(uint32_t flags);
+/* CPU-only diagnostic: GetHitColor in the reference's nesting L = (E+S) + a*(...) (spheres-app.cpp:249-251) instead of
+ * the forward radiance += throughput*(E+S) form that the path's contract (and the HIP kernel) uses */
+void orc_use_nested_radiance(int on);
 int orc_clear(orc_ctx* ctx);
 int orc_resolve(orc_ctx* ctx, uint32_t n_samples);
 int orc_download(orc_ctx* ctx, float* hdr_rgb, uint8_t* ldr_rgb);

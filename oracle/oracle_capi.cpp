@@ -83,6 +83,7 @@ int orc_render(orc_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, 
 
 void orc_use_reference_halton_counters(int on) { Random::UseReferenceHaltonCounters(on != 0); }
 void orc_set_sampler(uint32_t flags) { Random::SetSamplerFlags(flags); }
+void orc_use_nested_radiance(int on) { UseNestedRadiance(on != 0); }
 
 int orc_clear(orc_ctx* ctx) {
     if (!ctx) return Fail("orc_clear: null ctx");

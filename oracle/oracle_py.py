@@ -108,6 +108,8 @@ def lib():
         L.orc_use_reference_halton_counters.argtypes = [C.c_int]
         L.orc_set_sampler.argtypes = [C.c_uint32]
         L.orc_set_sampler.restype = None
+        L.orc_use_nested_radiance.argtypes = [C.c_int]
+        L.orc_use_nested_radiance.restype = None
         L.orc_clear.argtypes = [C.c_void_p]
         L.orc_resolve.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -598,7 +598,48 @@ std::optional<Payload> SpheresApp::GetClosestIntersection(const Ray& ray) const 
 // spheres-app.cpp:238-257, iterative: L = E0+S0 + a0*(E1+S1 + a1*(...)) carried as
 // radiance += throughput*(E+S); throughput *= attenuation.  Scatter is called FIRST (:246) and
 // still draws at depth == limit (:246-247).  Shade always receives the CAMERA origin (:250).
+static bool g_nestedRadiance = false;
+void UseNestedRadiance(bool on) { g_nestedRadiance = on; }
+bool NestedRadiance() { return g_nestedRadiance; }
+
+// The recursion exactly as the reference nests it (spheres-app.cpp:249-251):
+//     return Emit + Shade + (recurse ? attenuation * GetHitColor(scattered, depth + 1) : XM_Zero)
+// evaluated back to front over the recorded (Emit + Shade, attenuation) of every bounce.  CPU-only diagnostic mode:
+// the contract of the path (oracle default and HIP kernel) is the forward form above, which is algebraically equal
+// but rounds differently (the distributive law is not exact in binary32); tests bound the difference.
+XMVECTOR SpheresApp::GetHitColorNested(const Ray& ray0, int depth0) const {
+    std::vector<XMVECTOR> local, atten;
+    XMVECTOR tail = ORC_XM_Zero;  // what the innermost call returns beyond its own Emit + Shade
+    bool tailIsSky = false;
+    Ray ray = ray0;
+    for (int depth = depth0;; ++depth) {
+        if (auto hitInfo = GetClosestIntersection(ray)) {
+            const Payload& hit = hitInfo.value();
+            XMVECTOR attenuation;
+            Ray scatteredRay;
+            const bool isScattered = hit.material->Scatter(ray, hit, attenuation, scatteredRay);
+            const bool recurse = depth < m_maxDepth && isScattered;
+            local.push_back(hit.material->Emit(hit) + hit.material->Shade(hit, m_lights, m_camera->GetOrigin()));
+            atten.push_back(attenuation);
+            if (!recurse) break;
+            ray = scatteredRay;
+        } else {
+            tail = m_skyMaterial->Emit(Payload{});  // :255
+            tailIsSky = true;
+            break;
+        }
+    }
+    // innermost first: a miss returns the sky; a hit that does not recurse returns local + XM_Zero
+    XMVECTOR L = tailIsSky ? tail : ORC_XM_Zero;
+    for (size_t k = local.size(); k-- > 0;) {
+        const bool innermostHit = (k + 1 == local.size()) && !tailIsSky;
+        L = innermostHit ? local[k] + ORC_XM_Zero : local[k] + atten[k] * L;
+    }
+    return L;
+}
+
 XMVECTOR SpheresApp::GetHitColor(const Ray& ray0, int depth0) const {
+    if (g_nestedRadiance) return GetHitColorNested(ray0, depth0);
     XMVECTOR radiance = ORC_XM_Zero;
     XMVECTOR throughput = ORC_XM_One;
     Ray ray = ray0;

@@ -91,6 +91,11 @@ void ScriptDraws(const float* draws, uint32_t n);
 uint32_t ScriptDrawsUsed();
 }  // namespace Random
 
+// CPU-only diagnostic: evaluate GetHitColor in the reference's own nesting (spheres-app.cpp:249-251) instead of the
+// forward throughput form that is the path's contract (see GetHitColorNested in rt_oracle.cpp).
+void UseNestedRadiance(bool on);
+bool NestedRadiance();
+
 // ------------------------------------------------------------------ geometry
 struct alignas(16) Payload {  // ray-tracing.h:5-13
     XMVECTOR t;
@@ -306,6 +311,7 @@ public:
     Ray GeneratePrimaryRay(uint32_t W, uint32_t H, uint32_t i, uint32_t j, uint32_t s) const;
     std::optional<Payload> GetClosestIntersection(const Ray& ray) const;  // :224-236
     XMVECTOR GetHitColor(const Ray& ray, int depth0) const;               // :238-257 (iterative)
+    XMVECTOR GetHitColorNested(const Ray& ray, int depth) const;  // the reference's nesting, CPU-only diagnostic (rt_oracle.cpp)
 
     // DrawBitmap's trace loop (:174-184) over a row set and sample range, accumulating into hdr.
     void Render(uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1, uint32_t maxDepth, uint64_t seed,
