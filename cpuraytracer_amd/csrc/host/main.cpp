@@ -12,7 +12,8 @@
 static void Usage() {
     std::puts("usage: spheres [--width N] [--height N] [--spp N] [--frame-spp N] [--depth N] [--fov F] [--aperture F]\n"
               "               [--scene cover|three|grid10k] [--scene-seed N] [--seed N] [--device N] [--gpus N] [--out file.ppm] [--quiet]\n"
-              "               [--sampler reference|cosine|sqrtdisk|cosine+sqrtdisk]   (default: the reference's mappings)");
+              "               [--sampler reference|cosine|sqrtdisk|cosine+sqrtdisk]   (default: the reference's mappings)\n"
+              "               [--pipeline N]   frames in flight for quiet progressive runs (--frame-spp 1 --quiet); 0 = off");
 }
 
 int main(int argc, char** argv) {
@@ -41,6 +42,7 @@ int main(int argc, char** argv) {
         else if (k == "--gpus") gpus = std::atoi(val());
         else if (k == "--out") out = val();
         else if (k == "--quiet") quiet = true;
+        else if (k == "--pipeline") st.framesInFlight = (uint32_t)std::atoi(val());
         else if (k == "--sampler") {
             const std::string v = val();
             st.samplerFlags = (v.find("cosine") != std::string::npos ? RT_SAMPLER_COSINE_HEMISPHERE : 0u) |

@@ -25,6 +25,7 @@ struct AppSettingsT {
     uint64_t sceneSeed = 1;       // replaces std::random_device (spheres-app.cpp:53-54)
     uint64_t renderSeed = 1;      // per-path xoshiro stream seed
     uint32_t samplesPerFrame = 1; // the reference adds one sample per frame (spheres-app.cpp:168)
+    uint32_t framesInFlight = 0;  // rt_set_frame_pipelining: frames whose unfinished paths may ride along into later frames (0 = off)
     uint32_t samplerFlags = 0;    // RT_SAMPLER_* (rt_api.h): 0 = the reference's uniform hemisphere and linear-r lens disk
 };
 

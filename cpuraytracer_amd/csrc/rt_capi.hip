@@ -108,6 +108,20 @@ struct rt_ctx {
     uint32_t treeTop = 128;  // largest top level the matrix-core filter takes (4 tiles of 32); RT_TREE_TOP overrides
     bool forceGlobal = false;
     std::unordered_map<const void*, size_t> ldsAttr;  // dynamic-LDS limit last set per kernel variant (LaunchTrace)
+
+    // frame pipelining (rt_set_frame_pipelining; rt_params.h): regions of a sample ring, two continuation buffers
+    uint32_t pipeDepth = 0;     // calls a path may be carried across (0 = off)
+    bool pipeOpen = false;      // pipelined calls have been submitted since the last flush
+    uint32_t pipeSeq = 0;       // sequence number of the newest region
+    uint32_t pipeSppCap = 0, pipeNpix = 0, pipeRing = 0;  // geometry of the ring: samples per region, pixels, regions
+    uint32_t pipeInSel = 0;     // which continuation buffer the next trace kernel reads
+    uint32_t pipeMaxDepth = 0;  // max_depth and seed of the running pipeline (a flush re-launches with them)
+    uint64_t pipeSeed = 0;
+    rtd::RegionTable pipeRegions{};
+    DevBuf<float> ring;
+    DevBuf<rtd::ContEntry> cont[2];
+    DevBuf<uint32_t> contN[2];  // carried paths per wave
+    DevBuf<rtd::FrameCtl> ctl;
 };
 
 static uint32_t RowsetLocalRows(rt_rowset rs) {
@@ -525,9 +539,11 @@ static TraceVariant ChooseVariant(const rt_ctx* ctx, const rtd::TraceParams& tp)
     return V;
 }
 
-// Launch the megakernel over total paths described by tp.
-static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
-    RT_HIP(hipMemsetAsync(ctx->queue.ptr, 0, sizeof(uint32_t), ctx->stream));
+// Launch the megakernel over total paths described by tp.  carryMode 0: ordinary launch.  1: probe -- RT_OK iff this scene
+// and these settings get the kernel variant that implements frame pipelining (nothing is launched).  2: launch that variant
+// (tp.ctl etc. filled by the caller; the queue cursor lives in tp.ctl and is reset by the preparation kernel).
+static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
+    if (carryMode == 0) RT_HIP(hipMemsetAsync(ctx->queue.ptr, 0, sizeof(uint32_t), ctx->stream));
     tp.mats_in_lds = ctx->matsInLds ? 1u : 0u;
     const size_t lds = LdsBytesFor(tp.n, tp.n_padded, ctx->matsInLds);
     if (tp.n_padded >= 65536) return Fail(RT_ERR_INVALID_ARG, "scenes beyond 65,000 spheres are not supported by the 16-bit candidate lists");
@@ -538,6 +554,7 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
     uint32_t blocks = (uint32_t)((wavesNeeded + wavesPerBlock - 1) / wavesPerBlock);
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks == 0) blocks = 1;
+    if (carryMode == 2) blocks = maxBlocks;  // carried paths may outnumber the fresh ones (a flush has none)
     // dynamic LDS: per-wave candidate regions + the scene tables when they fit + the filter operand image
     const TraceVariant V = ChooseVariant(ctx, tp);
     const bool tree = V.tree, flat = V.flat, ldsTables = V.ldsTables;
@@ -563,6 +580,11 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
                      (flat || tree) ? MfmaOpsBytesFor(topCnt) : (size_t)0, sgBytes, treeBytes, tp.ray_cache_off16 ? "yes" : "no");
     // flat variant with the hit-processing tables provably in LDS (typed pointers: no flat loads) when they all fit
     const bool hitLds = flat && tp.mats_in_lds && (sgBytes != 0 || !tp.sg_enabled);
+    if (carryMode != 0) {
+        const bool ok = hitLds && tp.ray_cache_off16 != 0 && ctx->blockThreads == 1024;
+        if (carryMode == 1) return ok ? RT_OK : RT_ERR_INVALID_ARG;
+        if (!ok) return Fail(RT_ERR_INVALID_ARG, "frame pipelining needs the flat LDS variant of the trace kernel");
+    }
 #define RT_LAUNCH_K(KERNEL)                                                                                                   \
     do {                                                                                                                      \
         const void* fn_ = reinterpret_cast<const void*>(&KERNEL);                                                             \
@@ -589,7 +611,8 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
         else if (ctx->blockThreads == 512) RT_LAUNCH(LDS, 512, M);     \
         else RT_LAUNCH(LDS, 256, M);                                   \
     } while (0)
-    if (tree) RT_LAUNCH_T(false, 2);
+    if (carryMode == 2) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 1, true, true, true>));
+    else if (tree) RT_LAUNCH_T(false, 2);
     else if (flat) RT_LAUNCH_T(true, 1);
     else if (ldsTables) RT_LAUNCH_T(true, 0);
     else RT_LAUNCH_T(false, 0);
@@ -598,6 +621,150 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp) {
 #undef RT_LAUNCH_K
     RT_HIP(hipGetLastError());
     return RT_OK;
+}
+
+
+// ------------------------------------------------------------------------------ frame pipelining
+// (rt_params.h "frame pipelining")  Host side: one region of the sample ring per rt_render call, two
+// continuation buffers used alternately, and three launches per call: preparation + ray-generation tables, the carrying
+// trace kernel, the commit kernel.  Nothing here waits for the device.
+static void PipelineDrop(rt_ctx* ctx) { ctx->pipeOpen = false; }  // carried paths and uncommitted regions are abandoned
+static uint32_t PipelineWaves(const rt_ctx* ctx) { return (uint32_t)ctx->cuCount * ctx->blocksPerCu * (ctx->blockThreads / 64); }
+// The first static_blocks blocks of every wave are static; the remaining paths of the call are cut into eight shards.
+static rtd::ShardStarts PipelineShards(const rt_ctx* ctx, rtd::TraceParams& tp) {
+    rtd::ShardStarts st{};
+    const uint64_t total = tp.total_paths;
+    tp.static_blocks = EnvU32("RT_PIPE_STATIC_BLOCKS", 1);  // measured (tools/progressive_frames.py): 128 x 1 beats 64 x 2, 128 x 0, 192 x 1
+    tp.queue_block = EnvU32("RT_PIPE_QUEUE_BLOCK", rtd::kCarryQueueBlock) / 64u * 64u;
+    if (tp.queue_block == 0) tp.queue_block = 64;
+    const uint64_t qb = tp.queue_block;
+    uint64_t begin = (uint64_t)PipelineWaves(ctx) * qb * tp.static_blocks;
+    if (begin > total) begin = total;
+    const uint64_t blocks = (total - begin + qb - 1) / qb;
+    uint64_t at = begin;
+    for (uint32_t k = 0; k < rtd::kQueueShards; ++k) {
+        const uint64_t nb = blocks / rtd::kQueueShards + (k < blocks % rtd::kQueueShards ? 1 : 0);
+        uint64_t end = at + nb * qb;
+        if (end > total) end = total;
+        st.begin[k] = tp.shard_begin[k] = (uint32_t)at;
+        tp.shard_end[k] = (uint32_t)end;
+        at = end;
+    }
+    return st;
+}
+
+static int PipelineTraceAndCommit(rt_ctx* ctx, rtd::TraceParams& tp, uint32_t npix, bool carry) {
+    tp.ctl = ctx->ctl.ptr;
+    tp.cont_in = ctx->cont[ctx->pipeInSel].ptr;
+    tp.cont_in_n = ctx->contN[ctx->pipeInSel].ptr;
+    tp.cont_out = ctx->cont[ctx->pipeInSel ^ 1u].ptr;
+    tp.cont_out_n = ctx->contN[ctx->pipeInSel ^ 1u].ptr;
+    tp.carry = carry ? 1u : 0u;
+    tp.region_seq = ctx->pipeSeq;
+    tp.max_carry_age = ctx->pipeDepth;
+    tp.min_iters = EnvU32("RT_PIPE_MIN_ITERS", 8);
+    tp.queue_head = nullptr;  // the carrying kernel uses the sharded cursors in tp.ctl
+    tp.counters = ctx->counters.ptr;
+    int rc = LaunchTrace(ctx, tp, 2);
+    if (rc != RT_OK) return rc;
+    const uint32_t commitBlocks = std::min<uint32_t>((npix + 255) / 256, (uint32_t)ctx->cuCount * 2u);
+    hipLaunchKernelGGL(rtd::rt_commit_kernel, dim3(commitBlocks), dim3(256), 0, ctx->stream, ctx->ring.ptr, ctx->hdr.ptr, npix,
+                       npix * ctx->pipeSppCap, ctx->pipeRing, ctx->pipeRegions, ctx->ctl.ptr, ctx->pipeSeq);
+    RT_HIP(hipGetLastError());
+    ctx->pipeInSel ^= 1u;
+    return RT_OK;
+}
+
+// Run every carried path to its end and commit every region: afterwards the HDR strip holds ctx->accumulated samples.
+static int PipelineFlush(rt_ctx* ctx) {
+    if (!ctx->pipeOpen) return RT_OK;
+    const uint32_t npix = ctx->pipeNpix;
+    rtd::TraceParams tp = ctx->base;
+    tp.total_paths = 0;  // nothing fresh: only the carried paths
+    hipLaunchKernelGGL(rtd::rt_raygen_tables_kernel, dim3(1), dim3(256), 0, ctx->stream, (float2*)nullptr, 0u, 0u, (float2*)nullptr, 0u, 0u,
+                       ctx->sampler, ctx->ctl.ptr, PipelineShards(ctx, tp));
+    RT_HIP(hipGetLastError());
+    tp.W = ctx->W;
+    tp.H = ctx->H;
+    tp.rs = ctx->rs;
+    tp.s0 = 1;
+    tp.spp_pass = 1;
+    tp.npix_local = npix;
+    tp.max_depth = ctx->pipeMaxDepth;
+    tp.sampler = ctx->sampler;
+    tp.seed = ctx->pipeSeed;
+    tp.samples = ctx->ring.ptr;
+    int rc = PipelineTraceAndCommit(ctx, tp, npix, false);
+    ctx->pipeOpen = false;
+    if (rc != RT_OK) ctx->accumulated = 0;
+    return rc;
+}
+
+// One pipelined call: samples [s0, s1) of the strip become region pipeSeq + 1 of the ring.
+static int PipelineRender(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t npix, uint32_t s0, uint32_t s1, uint32_t max_depth,
+                          uint64_t seed) {
+    const uint32_t spp = s1 - s0;
+    const uint32_t nRing = ctx->pipeDepth + 2u;
+    int rc;
+    if (ctx->pipeOpen && (ctx->pipeNpix != npix || spp > ctx->pipeSppCap || ctx->pipeRing != nRing || ctx->pipeMaxDepth != max_depth ||
+                          ctx->pipeSeed != seed)) {
+        if ((rc = PipelineFlush(ctx)) != RT_OK) return rc;  // geometry or parameters changed: start a new pipeline
+    }
+    if (!ctx->pipeOpen) {
+        ctx->pipeNpix = npix;
+        ctx->pipeSppCap = spp;
+        ctx->pipeRing = nRing;
+        ctx->pipeMaxDepth = max_depth;
+        ctx->pipeSeed = seed;
+        ctx->pipeInSel = 0;
+        ctx->pipeRegions = rtd::RegionTable{};
+        const size_t waves = PipelineWaves(ctx);
+        if ((rc = ctx->ring.Reserve((size_t)nRing * npix * spp * 3)) != RT_OK) return rc;
+        for (int k = 0; k < 2; ++k) {
+            if ((rc = ctx->cont[k].Reserve(waves * 64)) != RT_OK) return rc;
+            if ((rc = ctx->contN[k].Reserve(waves)) != RT_OK) return rc;
+            RT_HIP(hipMemsetAsync(ctx->contN[k].ptr, 0, waves * sizeof(uint32_t), ctx->stream));  // nothing carried yet
+        }
+        if ((rc = ctx->ctl.Reserve(1)) != RT_OK) return rc;
+        rtd::FrameCtl init{};
+        init.oldest_open = 0xffffffffu;
+        init.committed_seq = ctx->pipeSeq;              // everything up to here is in the strip already
+        init.committed_samples = ctx->accumulated;
+        RT_HIP(hipMemcpyAsync(ctx->ctl.ptr, &init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(hipStreamSynchronize(ctx->stream));       // `init` is a stack object; once per pipeline start
+        ctx->pipeOpen = true;
+    }
+    const uint32_t seq = ++ctx->pipeSeq;
+    const uint32_t slot = seq % nRing;
+    ctx->pipeRegions.seq[slot] = seq;
+    ctx->pipeRegions.spp[slot] = spp;
+    rtd::TraceParams tp = ctx->base;
+    tp.W = W;
+    tp.H = H;
+    tp.rs = rs;
+    tp.s0 = s0;
+    tp.spp_pass = spp;
+    tp.total_paths = npix * spp;
+    tp.npix_local = npix;
+    tp.max_depth = max_depth;
+    tp.sampler = ctx->sampler;
+    tp.seed = seed;
+    tp.path_list = nullptr;
+    tp.samples = ctx->ring.ptr;
+    tp.sample_base = slot * npix * ctx->pipeSppCap;
+    tp.trav_out = nullptr;
+    const uint32_t k0 = s0 + rs.first_row;
+    const uint32_t nLens = spp + W + rs.num_rows;
+    if ((rc = ctx->jitterTab.Reserve(spp)) != RT_OK) return rc;
+    if ((rc = ctx->lensTab.Reserve(nLens)) != RT_OK) return rc;
+    tp.jitter_tab = ctx->jitterTab.ptr;
+    tp.lens_tab = ctx->lensTab.ptr;
+    tp.lens_k0 = k0;
+    const uint32_t nmax = spp > nLens ? spp : nLens;
+    hipLaunchKernelGGL(rtd::rt_raygen_tables_kernel, dim3((nmax + 255) / 256), dim3(256), 0, ctx->stream, ctx->jitterTab.ptr, s0, spp,
+                       ctx->lensTab.ptr, k0, nLens, ctx->sampler, ctx->ctl.ptr, PipelineShards(ctx, tp));
+    RT_HIP(hipGetLastError());
+    return PipelineTraceAndCommit(ctx, tp, npix, true);
 }
 
 namespace {
@@ -694,6 +861,12 @@ void rt_destroy(rt_ctx* ctx) {
     ctx->jitterTab.Release();
     ctx->lensTab.Release();
     ctx->leaf.Release();
+    ctx->ring.Release();
+    ctx->cont[0].Release();
+    ctx->cont[1].Release();
+    ctx->contN[0].Release();
+    ctx->contN[1].Release();
+    ctx->ctl.Release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : ctx->passEv)
@@ -810,18 +983,44 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     ctx->n = n;
     ctx->hasScene = true;
     ctx->accumulated = 0;
+    PipelineDrop(ctx);
+    return RT_OK;
+}
+
+int rt_set_frame_pipelining(rt_ctx* ctx, uint32_t depth) {
+    if (!ctx || depth > rtd::kMaxFramesInFlight - 2u) return Fail(RT_ERR_INVALID_ARG, "rt_set_frame_pipelining: depth must be 0..14");
+    RT_HIP(hipSetDevice(ctx->device));
+    int rc = PipelineFlush(ctx);
+    ctx->pipeDepth = depth;
+    return rc;
+}
+
+int rt_committed_samples(rt_ctx* ctx, uint32_t* out) {
+    if (!ctx || !out) return Fail(RT_ERR_INVALID_ARG, "rt_committed_samples: null argument");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    *out = ctx->accumulated;
+    if (ctx->pipeOpen) {
+        rtd::FrameCtl c{};
+        RT_HIP(hipMemcpy(&c, ctx->ctl.ptr, sizeof(c), hipMemcpyDeviceToHost));
+        *out = c.committed_samples;
+    }
     return RT_OK;
 }
 
 int rt_set_sampler(rt_ctx* ctx, uint32_t flags) {
     if (!ctx || (flags & ~(RT_SAMPLER_COSINE_HEMISPHERE | RT_SAMPLER_SQRT_DISK)) != 0u) return Fail(RT_ERR_INVALID_ARG, "rt_set_sampler: unknown flag");
-    if (flags != ctx->sampler) ctx->accumulated = 0;  // samples of two mappings do not mix: the next rt_render starts over
+    if (flags != ctx->sampler) {
+        ctx->accumulated = 0;  // samples of two mappings do not mix: the next rt_render starts over
+        PipelineDrop(ctx);
+    }
     ctx->sampler = flags;
     return RT_OK;
 }
 
 int rt_clear(rt_ctx* ctx) {
     if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_clear: null ctx");
+    PipelineDrop(ctx);
     ctx->accumulated = 0;
     return RT_OK;
 }
@@ -846,6 +1045,18 @@ int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, ui
     const uint32_t npix = (uint32_t)npix64;
 
     const bool sameStrip = ctx->W == W && ctx->H == H && ctx->rows == rows && std::memcmp(&ctx->rs, &rs, sizeof(rs)) == 0;
+    // frame pipelining: only calls that ask for no statistics may leave work in flight; anything else first settles it
+    bool pipelined = ctx->pipeDepth > 0 && out_stats == nullptr;
+    if (pipelined) {
+        rtd::TraceParams probe = ctx->base;
+        probe.total_paths = npix;
+        pipelined = LaunchTrace(ctx, probe, 1) == RT_OK && (uint64_t)npix * (s1 - s0) * (ctx->pipeDepth + 2u) < (1ull << 31);
+    }
+    if (s0 == 1 || ctx->accumulated == 0) PipelineDrop(ctx);  // a new accumulation abandons whatever was in flight
+    else if (!pipelined) {
+        int rcf = PipelineFlush(ctx);
+        if (rcf != RT_OK) return rcf;
+    }
     if (s0 == 1 || ctx->accumulated == 0) {
         if (s0 != 1) return Fail(RT_ERR_SEQUENCE, "rt_render: first call of an accumulation must start at s0 == 1");
         int rc;
@@ -859,6 +1070,17 @@ int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, ui
         ctx->accumulated = 0;
     } else if (!sameStrip || s0 != ctx->accumulated + 1) {
         return Fail(RT_ERR_SEQUENCE, "rt_render: sample range or row set does not continue the accumulation");
+    }
+
+    if (pipelined) {
+        int rcp = PipelineRender(ctx, W, H, rs, npix, s0, s1, max_depth, seed);
+        if (rcp != RT_OK) {
+            ctx->accumulated = 0;
+            PipelineDrop(ctx);
+            return rcp;
+        }
+        ctx->accumulated += s1 - s0;
+        return RT_OK;
     }
 
     // split [s0, s1) into passes whose sample buffer fits the workspace limit
@@ -969,7 +1191,10 @@ int rt_resolve(rt_ctx* ctx, uint32_t n_samples) {
     const uint32_t n = n_samples ? n_samples : ctx->accumulated;
     const uint32_t npix = ctx->W * ctx->rows;
     RT_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL(rtd::rt_resolve_kernel, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, ctx->hdr.ptr, ctx->ldr.ptr, npix, n);
+    // with frames in flight the strip holds FrameCtl::committed_samples samples, a number only the device knows
+    const uint32_t* devCount = (ctx->pipeOpen && n_samples == 0) ? &ctx->ctl.ptr->committed_samples : nullptr;
+    hipLaunchKernelGGL(rtd::rt_resolve_kernel, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, ctx->hdr.ptr, ctx->ldr.ptr, npix, n,
+                       devCount);
     RT_HIP(hipGetLastError());
     RT_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     RT_HIP(hipEventSynchronize(ctx->ev[1]));
@@ -1005,6 +1230,8 @@ int rt_copy_to_device(rt_ctx* ctx, void* dev_hdr_rgb, void* dev_ldr_rgb) {
 int rt_synchronize(rt_ctx* ctx) {
     if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_synchronize: null ctx");
     RT_HIP(hipSetDevice(ctx->device));
+    int rcf = PipelineFlush(ctx);  // frames in flight are finished and committed first
+    if (rcf != RT_OK) return rcf;
     RT_HIP(hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
@@ -1228,6 +1455,19 @@ int rt_unit_layout(const rt_sphere* spheres, uint32_t n, uint32_t cap_groups, ui
     std::memcpy(bounds, L.tree.data(), (size_t)L.nGroups * sizeof(float4));  // level 0 comes first
     return RT_OK;
 }
+
+#ifdef RT_TIMELINE
+// Diagnostic build only: wall-clock landmarks (100 MHz ticks) of the trace kernels since the last call; then reset.
+int rt_debug_timeline(rt_ctx* ctx, unsigned long long out[16]) {
+    if (!ctx || !out) return Fail(RT_ERR_INVALID_ARG, "rt_debug_timeline: invalid argument");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(rtd::g_tl), 16 * sizeof(unsigned long long)));
+    unsigned long long z[16] = {~0ull, 0, 0, 0, 0, 0, ~0ull, ~0ull, 0, 0, 0, 0, 0, 0, 0, 0};
+    RT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_tl), z, sizeof(z)));
+    return RT_OK;
+}
+#endif
 
 #ifdef RT_STAMPS
 // Diagnostic build only: read and clear the section clocks (see rt_params.h g_dbg).

@@ -73,7 +73,7 @@ RT_DEV void path_coordinates(const TraceParams& p, uint32_t q, uint32_t& i, uint
         const uint32_t lr = pl / p.W;
         i = pl - lr * p.W;
         j = rowset_global_row(p.rs, lr);
-        slot = q;
+        slot = q + p.sample_base;  // the call's region of the sample ring (0 without frame pipelining)
     }
 }
 
@@ -188,9 +188,15 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
 // max_depth+1 segments have finished.
 // kScan: 0 = VALU sign filter per group (any scene size), 1 = matrix-core filter over the groups (tables in LDS),
 // 2 = matrix-core filter over the top level of the bounds hierarchy + per-lane descent (tables through L2).
-template <bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds = false>
+// kCarry: frame pipelining (rt_params.h): resume the paths the previous trace kernel carried out, end as soon as the
+// fresh queue is empty and carry the unfinished paths into the next kernel.
+template <bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds = false, bool kCarry = false>
 __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams p) {
     constexpr bool kMfma = kScan != 0;
+    static_assert(!kCarry || (kCache && kHitLds && kScan == 1), "frame pipelining is built for the flat LDS variant only");
+#ifdef RT_TIMELINE
+    const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz; diagnostic build only
+#endif
     extern __shared__ float4 smem[];
     // [0, kConstBytes): the scene constants; then the per-wave regions; then the tables
     SceneConsts* ldsK = reinterpret_cast<SceneConsts*>(smem);
@@ -228,6 +234,9 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     uint16_t* waveCand = candBase + (threadIdx.x / kWaveSize) * (kWaveRegion / 2);
     uint16_t* cand = waveCand + lane;
     __syncthreads();  // the constants block (and, above, the staged tables) are visible to every wave from here on
+#ifdef RT_TIMELINE
+    const unsigned long long tl1 = __builtin_amdgcn_s_memrealtime();
+#endif
     const SceneConsts& K = *ldsK;
     const V3 sunDir = v3(K.sun_dir[0], K.sun_dir[1], K.sun_dir[2]);
     const float aSun = dot3(sunDir, sunDir);  // the `a` of every shadow ray (ray-tracing.cpp:46)
@@ -238,12 +247,47 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     V3 pend = v3(0.f, 0.f, 0.f), nextDir = v3(0.f, 0.f, 0.f);
     StreamDraws draws{Rng{1u, 0u, 0u, 0u}};
     uint32_t q = 0, depth = 0, state = kIdle, pathTrav = 0;  // q = the path's slot in the sample buffer
+    uint32_t seq8 = 0;  // kCarry: low byte of the sequence number of the path's region (its call)
+    uint32_t carried = 0;  // kCarry: paths this wave carries out (wave-uniform)
+    uint32_t itersHere = 0;  // kCarry: iterations of this wave in this launch
+    const uint32_t gwave = blockIdx.x * (kThreads / kWaveSize) + threadIdx.x / kWaveSize;  // this wave's index in the grid
+    const uint32_t kBlk = kCarry ? p.queue_block : kQueueBlock;  // paths per queue block
     bool contAfterShadow = false, pathScattered = false;
     uint32_t nTrav = 0, nSeg = 0;
 
     // wave-uniform queue window and prepared-path cache (48-byte slots: origin, direction, stream state, path index)
     uint32_t blkNext = 0, blkEnd = 0, cachePos = 0, cacheCnt = 0;
     bool queueEmpty = false;
+    if (kCarry) {
+        // the wave's own carried paths (rt_params.h): no cursor, no atomics
+        const uint32_t nIn = p.cont_in_n[gwave];
+        if (lane < nIn) {
+            const ContEntry* e = p.cont_in + ((size_t)gwave * kWaveSize + lane);
+            const float4 A = e->a, B = e->b, Cc = e->c, D = e->d, E = e->e;
+            ro = v3(A.x, A.y, A.z);
+            rd = v3(A.w, B.x, B.y);
+            thr = v3(B.z, B.w, Cc.x);
+            rad = v3(Cc.y, Cc.z, Cc.w);
+            draws.rng = Rng{__float_as_uint(D.x), __float_as_uint(D.y), __float_as_uint(D.z), __float_as_uint(D.w)};
+            q = __float_as_uint(E.x);
+            depth = __float_as_uint(E.y);
+            seq8 = __float_as_uint(E.z);
+            pathTrav = __float_as_uint(E.w);
+            const float4 F = e->f, G = e->g;
+            pend = v3(F.x, F.y, F.z);
+            nextDir = v3(F.w, G.x, G.y);
+            const uint32_t fl = __float_as_uint(G.z);
+            state = fl & 3u;
+            contAfterShadow = (fl & 4u) != 0u;
+            pathScattered = (fl & 8u) != 0u;
+        }
+        // ... and its first block of fresh paths is static too: block `gwave`; the shared cursor starts behind those.
+        // Blocks are half the usual size here: a wave can only start paths as lanes fall idle, so a wave whose lanes are held
+        // by long paths should own little unstarted work when the queue runs dry (it must start all of it before it may leave).
+        const uint32_t b0 = gwave * (kBlk * p.static_blocks);
+        blkNext = b0 < p.total_paths ? b0 : p.total_paths;
+        blkEnd = (b0 + kBlk * p.static_blocks) < p.total_paths ? (b0 + kBlk * p.static_blocks) : p.total_paths;
+    }
     float4* rayCache = kCache ? smem + p.ray_cache_off16 + (threadIdx.x / kWaveSize) * (kRayCacheBytes / 16) : nullptr;
 
     unsigned long long dbgScan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -266,13 +310,39 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                     if (queueEmpty) break;
                     if (blkNext == blkEnd) {
                         uint32_t b = 0;
-                        if (lane == 0) b = atomicAdd(p.queue_head, kQueueBlock);
-                        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                        blkNext = b < p.total_paths ? b : p.total_paths;
-                        blkEnd = (b + kQueueBlock) < p.total_paths ? (b + kQueueBlock) : p.total_paths;
-                        if (b >= p.total_paths) {
-                            queueEmpty = true;
-                            break;
+                        if (kCarry) {
+                            // sharded queue: the workgroup's own shard first, then the others.  Look before claiming: thousands
+                            // of waves find a shard empty within microseconds of each other, and a load is served from L2
+                            // while same-address atomics queue up one behind the other.
+                            bool got = false;
+                            for (uint32_t a = 0; a < kQueueShards && !got; ++a) {
+                                const uint32_t k = (blockIdx.x + a) & (kQueueShards - 1u);
+                                uint32_t* head = &p.ctl->shard_head[k][0];
+                                const uint32_t endK = p.shard_end[k];
+                                if (lane == 0) b = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                                if (b >= endK) continue;
+                                if (lane == 0) b = atomicAdd(head, kBlk);
+                                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                                if (b < endK) {
+                                    blkNext = b;
+                                    blkEnd = (b + kBlk) < endK ? (b + kBlk) : endK;
+                                    got = true;
+                                }
+                            }
+                            if (!got) {
+                                queueEmpty = true;
+                                break;
+                            }
+                        } else {
+                            if (lane == 0) b = atomicAdd(p.queue_head, kBlk);
+                            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                            blkNext = b < p.total_paths ? b : p.total_paths;
+                            blkEnd = (b + kBlk) < p.total_paths ? (b + kBlk) : p.total_paths;
+                            if (b >= p.total_paths) {
+                                queueEmpty = true;
+                                break;
+                            }
                         }
                     }
                     const uint32_t nGen = (blkEnd - blkNext) < (uint32_t)kWaveSize ? (blkEnd - blkNext) : (uint32_t)kWaveSize;
@@ -308,6 +378,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                     rad = v3(0.f, 0.f, 0.f);
                     depth = 0;
                     pathTrav = 0;
+                    if (kCarry) seq8 = p.region_seq & 255u;
                     state = kNeedClosest;
                 }
                 cachePos += want < avail ? want : avail;
@@ -345,6 +416,48 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
             }
         }
         if (__ballot(state != kIdle) == 0ull) break;  // queue empty and every lane drained
+        if (kCarry) {
+            ++itersHere;
+            // Nothing left to start: carry the live paths into the next call's kernel instead of running their tail here.
+            // A lane is carried between two scans, whichever it waits for (closest hit, or the shadow scan of a far hit point),
+            // but not when its region is max_carry_age calls old (its slot of the sample ring is about to be reused): such
+            // paths make the wave iterate on (<= 102 iterations).
+            // (min_iters: a wave without fresh work must still advance the paths it was handed, or they would be passed from
+            // kernel to kernel untouched until the age limit makes some wave run their whole tail)
+            const bool nothingToStart = queueEmpty && cachePos == cacheCnt && p.carry != 0u && itersHere >= p.min_iters;
+            const bool carriable = state == kIdle || ((p.region_seq - seq8) & 255u) < p.max_carry_age;
+#ifdef RT_TIMELINE
+            if (lane == 0 && itersHere > 14u) {
+                if (!queueEmpty) atomicAdd(&g_tl[8], 1ull);
+                else if (cachePos != cacheCnt) atomicAdd(&g_tl[9], 1ull);
+                else if (__ballot(!carriable) != 0ull) atomicAdd(&g_tl[10], 1ull);
+                else atomicAdd(&g_tl[11], 1ull);
+            }
+#endif
+            if (nothingToStart && __ballot(!carriable) == 0ull) {
+                const uint64_t liveMask = __ballot(state != kIdle);
+                carried = (uint32_t)__popcll(liveMask);
+                uint32_t age1 = 0;  // 1 + region age of this lane's carried path
+                if (state != kIdle) {
+                    ContEntry* e = p.cont_out + ((size_t)gwave * kWaveSize + prefix_count(liveMask));
+                    e->a = make_float4(ro.x, ro.y, ro.z, rd.x);
+                    e->b = make_float4(rd.y, rd.z, thr.x, thr.y);
+                    e->c = make_float4(thr.z, rad.x, rad.y, rad.z);
+                    e->d = make_float4(__uint_as_float(draws.rng.s0), __uint_as_float(draws.rng.s1), __uint_as_float(draws.rng.s2),
+                                       __uint_as_float(draws.rng.s3));
+                    e->e = make_float4(__uint_as_float(q), __uint_as_float(depth), __uint_as_float(seq8), __uint_as_float(pathTrav));
+                    e->f = make_float4(pend.x, pend.y, pend.z, nextDir.x);
+                    e->g = make_float4(nextDir.y, nextDir.z, __uint_as_float(state | (contAfterShadow ? 4u : 0u) | (pathScattered ? 8u : 0u)), 0.f);
+                    age1 = 1u + ((p.region_seq - seq8) & 255u);
+                }
+                for (int off = 32; off > 0; off >>= 1) {
+                    const uint32_t o2 = (uint32_t)__shfl_xor((int)age1, off);
+                    age1 = o2 > age1 ? o2 : age1;
+                }
+                if (lane == 0) atomicMax(&ldsK->exit_age_max, age1);  // LDS: the workgroup's oldest carried region
+                break;
+            }
+        }
 
         RT_STAMP(ts1);
         // ------------------------------------------------ one list scan for every live lane
@@ -463,6 +576,32 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
 #endif
     }
 
+    if (kCarry) {
+        // the wave that leaves last tells the commit kernel which region is the oldest with paths still in flight
+        if (lane == 0) {
+            p.cont_out_n[gwave] = carried;
+            const uint32_t ticket = atomicAdd(&ldsK->exit_ticket, 1u);
+            if (ticket == (uint32_t)(kThreads / kWaveSize) - 1u) {
+                const uint32_t m = atomicMax(&ldsK->exit_age_max, 0u);
+                if (m != 0u) atomicMin(&p.ctl->oldest_open, p.region_seq - (m - 1u));
+            }
+        }
+    }
+#ifdef RT_TIMELINE
+    if (lane == 0) {  // g_tl: [0] min start, [1] max staged, [2] max loop exit, [3] sum of (exit - start), [4] waves, [5] sum iterations
+        const unsigned long long tl2 = __builtin_amdgcn_s_memrealtime();
+        atomicMin(&g_tl[0], tl0);
+        atomicMax(&g_tl[1], tl1);
+        atomicMax(&g_tl[2], tl2);
+        atomicAdd(&g_tl[3], tl2 - tl0);
+        atomicAdd(&g_tl[4], 1ull);
+        atomicAdd(&g_tl[5], (unsigned long long)itersHere);
+        atomicMin(&g_tl[6], tl1);
+        atomicMin(&g_tl[7], tl2);
+        atomicMax(&g_tl[12], (unsigned long long)itersHere);
+        if (itersHere > 14u) atomicAdd(&g_tl[13], 1ull);
+    }
+#endif
     // counters: wave reduce, one atomic pair per wave
     unsigned long long t = nTrav, s = nSeg;
     for (int off = 32; off > 0; off >>= 1) {
@@ -503,9 +642,16 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
 
 // ============================================================ ray-generation tables (A1, A9)
 // jitter[k] = Halton2D(s0+k; 2,3) (spheres-app.cpp:140), lens[k] = HaltonSampleDisk(k0+k; 4,5) (:152)
+// Frame pipelining: the first threads also reset the cursors of the pipeline's control block for the trace kernel that follows.
+struct ShardStarts {
+    uint32_t begin[kQueueShards];
+};
 __global__ void __launch_bounds__(256) rt_raygen_tables_kernel(float2* jitter, uint32_t s0, uint32_t nJitter, float2* lens, uint32_t k0,
-                                                               uint32_t nLens, uint32_t sampler) {
+                                                               uint32_t nLens, uint32_t sampler, FrameCtl* ctl = nullptr,
+                                                               ShardStarts shards = ShardStarts{}) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ctl && k < kQueueShards) ctl->shard_head[k][0] = shards.begin[k];
+    if (ctl && k == 0) ctl->oldest_open = 0xffffffffu;
     if (k < nJitter) jitter[k] = make_float2(halton(s0 + k, 2), halton(s0 + k, 3));
     if (k < nLens) {
         float lx, ly;
@@ -549,6 +695,57 @@ __global__ void __launch_bounds__(256) rt_accumulate_kernel(const float* __restr
     hdr[3 * (size_t)pix + 2] = b;
 }
 
+// ================================================== ordered accumulation of pipelined regions (A16)
+// Frame pipelining: add every region that is complete -- sequence numbers committed+1 .. min(newest, oldest_open - 1) -- to
+// the HDR strip, region by region and sample by sample in increasing s (spheres-app.cpp:182-183), then let the block that
+// finishes last publish the new commit point.  Every block reads the same committed_seq / oldest_open: they are only
+// written by that last block and by the trace kernel before this one.
+struct RegionTable {
+    uint32_t seq[kMaxFramesInFlight];  // by ring slot (sequence % regions): the call that owns it
+    uint32_t spp[kMaxFramesInFlight];  // ... and its samples per pixel
+};
+__global__ void __launch_bounds__(256) rt_commit_kernel(const float* __restrict__ ring, float* __restrict__ hdr, uint32_t npix,
+                                                        uint32_t regionEntries, uint32_t nRing, RegionTable rt, FrameCtl* ctl,
+                                                        uint32_t newestSeq) {
+    const uint32_t committed = ctl->committed_seq, open = ctl->oldest_open;
+    uint32_t limit = newestSeq;
+    if (open != 0xffffffffu && open - 1u < limit) limit = open - 1u;
+    // a few hundred blocks striding over the pixels: the closing ticket is one same-address atomic per block
+    for (uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x; pix < npix && limit > committed; pix += gridDim.x * blockDim.x) {
+        float r = hdr[3 * (size_t)pix], g = hdr[3 * (size_t)pix + 1], b = hdr[3 * (size_t)pix + 2];
+        const uint32_t nFull = npix >> 6, tile = pix >> 6;
+        const uint32_t stride = tile < nFull ? 64u : npix - (nFull << 6);
+        for (uint32_t q = committed + 1u; q <= limit; ++q) {
+            const uint32_t slot = q % nRing, spp = rt.spp[slot];
+            // the region's buffer is tiled like the one-shot sample buffer: [tile of 64 pixels][sample][pixel in tile]
+            const float3* sp = reinterpret_cast<const float3*>(ring) + (size_t)slot * regionEntries + (size_t)tile * 64u * spp + (pix - (tile << 6));
+            for (uint32_t s = 0; s < spp; ++s) {
+                const float3 v = sp[(size_t)s * stride];
+                r += v.x;
+                g += v.y;
+                b += v.z;
+            }
+        }
+        hdr[3 * (size_t)pix] = r;
+        hdr[3 * (size_t)pix + 1] = g;
+        hdr[3 * (size_t)pix + 2] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const uint32_t t = atomicAdd(&ctl->acc_ticket, 1u);
+        if (t == gridDim.x - 1u) {
+            if (limit > committed) {
+                uint32_t add = 0;
+                for (uint32_t q = committed + 1u; q <= limit; ++q) add += rt.spp[q % nRing];
+                ctl->committed_seq = limit;
+                ctl->committed_samples += add;
+            }
+            ctl->acc_ticket = 0u;
+        }
+    }
+}
+
 // ====================================================================== resolve (A17)
 // hdr / n, ACES fit, gamma 1/2.2, XMStoreColor (spheres-app.cpp:186-214); output R,G,B bytes.
 RT_DEV float tonemap_channel(float h, float n) {
@@ -558,10 +755,12 @@ RT_DEV float tonemap_channel(float h, float n) {
     color = rt_powf(color, 1 / 2.2f);
     return color;
 }
+// committedSamples (frame pipelining): the number of samples in the strip is only known on the device
 __global__ void __launch_bounds__(256) rt_resolve_kernel(const float* __restrict__ hdr, uint8_t* __restrict__ ldr, uint32_t npix,
-                                                         uint32_t nSamples) {
+                                                         uint32_t nSamples, const uint32_t* committedSamples = nullptr) {
     const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= npix) return;
+    if (committedSamples) nSamples = *committedSamples > 0u ? *committedSamples : 1u;
     const float n = (float)nSamples;
     for (int ch = 0; ch < 3; ++ch) ldr[3 * (size_t)pix + ch] = (uint8_t)rne_u8(tonemap_channel(hdr[3 * (size_t)pix + ch], n));
 }

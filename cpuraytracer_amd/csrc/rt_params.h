@@ -30,9 +30,40 @@ RT_DEV unsigned long long rt_stamp() {
 #define RT_ACC(sum, a, b)
 #endif
 
+#ifdef RT_TIMELINE
+static __device__ unsigned long long g_tl[16];  // diagnostic build only: wall-clock landmarks of the last trace kernel
+#endif
+
 constexpr int kWaveSize = 64;
 constexpr uint32_t kMaxLevels = 6;  // levels of group bounds (4-ary): 128 * 4^5 groups at most
 constexpr uint32_t kQueueBlock = 256;  // paths a wave takes from the global queue per atomic
+constexpr uint32_t kCarryQueueBlock = 128; // ... in the frame-pipelining kernel (rt_kernels.h): two batches of the path cache
+
+// ---- frame pipelining (progressive use: SpheresApp::OnRender adds ONE sample per frame, spheres-app.cpp:163-184).
+// A 1-spp frame is 0.13 ms of work followed by the tail of its few 51-segment paths; with pipelining the trace kernel of
+// frame j ends as soon as the fresh queue is empty and CARRIES its unfinished paths (80-byte entries) into the kernel of
+// frame j+1.  Each rt_render call owns one region of a ring of sample buffers; regions are added to the HDR strip strictly in
+// call order, and only once no carried path belongs to them (FrameCtl::oldest_open).
+struct ContEntry {
+    float4 a, b, c, d, e;  // ro.xyz rd.x | rd.yz thr.xy | thr.z rad.xyz | xoshiro s0..s3 | slot, depth, region sequence & 255, traversals
+    float4 f, g;           // a lane waiting for its shadow scan (far hit point): pend.xyz nextDir.x | nextDir.yz, state and flags, -
+};
+// Carried paths stay with their wave: wave w of the (always full) grid writes its <= 64 entries to slots [64 w, 64 w + n) of
+// the outgoing buffer and n to the outgoing count array, and wave w of the next kernel restores exactly those -- no cursor,
+// no atomics.  (A first version claimed entries, fresh blocks and output slots with atomics on one control block: ~27,000
+// same-line atomics per 1-spp frame, which one L2 channel serialises at ~11 ns each -- 0.3 ms per frame.)
+// Fresh paths: every wave owns TraceParams::static_blocks blocks of 64 statically; the rest of the call's paths sits in eight
+// queue shards (one per XCD, a workgroup prefers shard blockIdx & 7 and steals from the others when its own is dry) whose
+// cursors are 128 bytes apart: ~7,000 claims per 1-spp frame spread over eight L2 lines instead of one.
+constexpr uint32_t kQueueShards = 8;
+struct FrameCtl {            // device control block of one context's pipeline
+    uint32_t shard_head[kQueueShards][32];  // [k][0]: cursor of queue shard k (reset before every trace kernel)
+    uint32_t oldest_open;    // min region sequence among the paths carried out of the last trace kernel (0xffffffff: none)
+    uint32_t committed_seq;  // regions with sequence <= this are in the HDR strip
+    uint32_t committed_samples;  // samples per pixel in the HDR strip
+    uint32_t acc_ticket;     // blocks of the commit kernel that have finished (the last one publishes committed_*)
+};
+constexpr uint32_t kMaxFramesInFlight = 16;  // regions of the sample ring
 
 struct TraceParams {
     // scene
@@ -83,6 +114,20 @@ struct TraceParams {
     uint32_t lens_k0;
     float* samples;             // [total_paths][3] radiance * exposure
     uint32_t* trav_out;         // optional per-path traversal counts
+    // frame pipelining (kCarry kernels only; all zero otherwise)
+    FrameCtl* ctl;
+    const ContEntry* cont_in;   // [waves][64] entries carried out of the previous trace kernel ...
+    const uint32_t* cont_in_n;  // ... and how many of them each wave left
+    ContEntry* cont_out;        // where this kernel carries its unfinished paths
+    uint32_t* cont_out_n;
+    uint32_t carry;             // 1: end when the fresh queue is empty and carry the live paths; 0: run every path to its end
+    uint32_t region_seq;        // sequence number of this call's region
+    uint32_t max_carry_age;     // a path whose region is this many calls old (or older) is finished in place, not carried
+    uint32_t min_iters;         // iterations a wave runs before it may carry its paths out
+    uint32_t queue_block;       // paths per queue block in the carrying kernel (a multiple of 64)
+    uint32_t static_blocks;     // blocks every wave owns without asking (block index = wave index)
+    uint32_t shard_begin[kQueueShards], shard_end[kQueueShards];  // path ranges of the queue shards (multiples of 64)
+    uint32_t sample_base;       // first 12-byte slot of this call's region in the sample ring (0 without pipelining)
     uint32_t ray_cache_off16;  // float4 offset of the per-wave prepared-path caches in dynamic LDS, 0 = no cache
     uint32_t* queue_head;       // global work counter, zeroed before launch
     unsigned long long* counters;  // [0] traversals, [1] segments
@@ -104,6 +149,8 @@ struct SceneConsts {
     uint32_t sampler;
     const float2* jitter_tab;
     const float2* lens_tab;
+    uint32_t exit_age_max;  // frame pipelining: 1 + the largest region age among the paths this workgroup carried out (0: none)
+    uint32_t exit_ticket;   // waves of this workgroup that have left the loop
 };
 constexpr uint32_t kSceneConstBytes = 256;                         // SceneConsts at the start of the dynamic LDS image ...
 constexpr uint32_t kConstBytes = kSceneConstBytes + 8 * 256;       // ... followed by the elementary functions' tables (255 words)
@@ -120,6 +167,7 @@ RT_DEV void fill_consts(const TraceParams& p, SceneConsts& k) {
     k.sg_nx = p.sg_nx; k.sg_ny = p.sg_ny; k.sg_nglobal = p.sg_nglobal; k.sg_enabled = p.sg_enabled;
     k.W = p.W; k.H = p.H; k.s0 = p.s0; k.lens_k0 = p.lens_k0; k.sampler = p.sampler;
     k.jitter_tab = p.jitter_tab; k.lens_tab = p.lens_tab;
+    k.exit_age_max = 0u; k.exit_ticket = 0u;
 }
 
 // --------------------------------------------------------------------------- row sets

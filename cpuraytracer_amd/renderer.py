@@ -41,6 +41,15 @@ class HipRenderer:
         """RT_SAMPLER_* flags (0 = the reference's uniform hemisphere and linear-r disk)."""
         check(self._L.rt_set_sampler(self._h, int(flags)))
 
+    def set_frame_pipelining(self, depth):
+        """rt_set_frame_pipelining: up to `depth` stats-less render calls may stay in flight (0 = off)."""
+        check(self._L.rt_set_frame_pipelining(self._h, int(depth)))
+
+    def committed_samples(self):
+        n = C.c_uint32(0)
+        check(self._L.rt_committed_samples(self._h, C.byref(n)))
+        return n.value
+
     def upload(self, scene):
         """scene: object with .spheres/.materials (numpy structured arrays in the rt_api.h layouts), .camera, .sun,
         .sky (ctypes structs of identical layout), .exposure_scale."""

@@ -173,6 +173,19 @@ int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, ui
 #define RT_SAMPLER_SQRT_DISK 2u
 int rt_set_sampler(rt_ctx* ctx, uint32_t flags);
 
+/* Frame pipelining for progressive use — the reference's only mode: OnRender adds ONE sample per pixel per frame
+ * (spheres-app.cpp:163-184, app.cpp:56-76).  A 1-spp frame is 0.13 ms of work followed by the tail of its few 51-segment
+ * paths.  With depth > 0, an rt_render call that passes out_stats == NULL returns with up to `depth` of the newest calls'
+ * sample planes still in flight: its kernel ends when nothing is left to start and carries the unfinished paths into the
+ * next call's kernel.  Planes are added to the HDR strip strictly in sample order as they complete, so after a flush the
+ * strip equals the one-shot render bit for bit.  While frames are in flight rt_resolve(ctx, 0) divides by the number of
+ * samples actually in the strip (rt_committed_samples), and rt_download / rt_copy_to_device hand out that strip.
+ * rt_synchronize, a call with statistics, rt_set_frame_pipelining itself and scenes the pipelined kernel variant does not
+ * cover (deeper bounds hierarchy, non-default launch knobs) settle everything first / run unpipelined.  depth 0 = off. */
+int rt_set_frame_pipelining(rt_ctx* ctx, uint32_t depth);
+/* Samples per pixel in the HDR strip right now (waits for the stream). */
+int rt_committed_samples(rt_ctx* ctx, uint32_t* out);
+
 /* Forget the accumulated HDR strip and sample count. */
 int rt_clear(rt_ctx* ctx);
 

@@ -573,6 +573,68 @@ def test_c4_full_size_depth_of_field(hip, oracle, scenes_mod):
         assert list(out) == list(ldr[j, i])
 
 
+# ------------------------------------------------------------------- frame pipelining (progressive use)
+@pytest.mark.parametrize("W,H,frames,spf,depth", [(1200, 800, 48, 1, 4), (161, 103, 40, 1, 2), (320, 200, 12, 3, 6), (96, 64, 30, 1, 1)])
+def test_pipelined_progressive_frames_equal_the_one_shot_render(hip, scenes_mod, W, H, frames, spf, depth):
+    """rt_set_frame_pipelining: stats-less 1-spp (or 3-spp) frames whose kernels carry their unfinished paths into the next
+    frame's kernel.  (a) a download in mid-stream returns exactly the one-shot image of the samples committed so far (planes
+    are added strictly in order); (b) after rt_synchronize the strip equals the one-shot render of all samples bit for bit."""
+    from cpuraytracer_amd import HipRenderer
+    sc = scenes_mod.build_scene("cover", 1, W, H)
+    one = HipRenderer(0)
+    one.upload(sc)
+    hip.upload(sc)
+    try:
+        hip.set_frame_pipelining(depth)
+        for f in range(frames):
+            hip.render(W, H, 1 + f * spf, 1 + (f + 1) * spf, 50, 1, stats=False)
+            if f == frames // 2:
+                c = hip.committed_samples()
+                assert 0 <= c <= (f + 1) * spf and c % spf == 0 and c >= (f + 1 - depth) * spf - spf
+                if c > 0:
+                    hip.resolve()
+                    h_mid, l_mid = hip.download()
+                    one.render(W, H, 1, 1 + c, 50, 1)
+                    one.resolve()
+                    h_ref, l_ref = one.download()
+                    assert_same(h_mid, h_ref, "strip in mid-stream (%d of %d samples committed)" % (c, (f + 1) * spf))
+                    assert_same(l_mid, l_ref, "LDR in mid-stream")
+        hip.synchronize()
+        assert hip.committed_samples() == frames * spf
+        hip.resolve()
+        hdr, ldr = hip.download()
+        one.render(W, H, 1, 1 + frames * spf, 50, 1)
+        one.resolve()
+        h1, l1 = one.download()
+        assert_same(hdr, h1, "pipelined frames vs one shot")
+        assert_same(ldr, l1, "pipelined frames vs one shot, LDR")
+        # a call with statistics settles the pipeline and continues the same accumulation
+        st = hip.render(W, H, 1 + frames * spf, 2 + frames * spf, 50, 1)
+        assert st.samples == W * H
+        one.render(W, H, 1 + frames * spf, 2 + frames * spf, 50, 1)
+        assert_same(hip.download(ldr=False)[0], one.download(ldr=False)[0], "continuation after the pipeline")
+    finally:
+        hip.set_frame_pipelining(0)
+        one.close()
+
+
+def test_pipelining_falls_back_where_the_variant_does_not_apply(hip, scenes_mod):
+    """grid10k runs the hierarchy scan, which has no carrying variant: the same calls run unpipelined and stay exact."""
+    sc = scenes_mod.build_scene("grid10k", 1, 96, 96)
+    hip.upload(sc)
+    hip.render(96, 96, 1, 5, 50, 1)
+    want = hip.download(ldr=False)[0]
+    try:
+        hip.set_frame_pipelining(3)
+        for s in range(1, 5):
+            hip.render(96, 96, s, s + 1, 50, 1, stats=False)
+        hip.synchronize()
+        assert hip.committed_samples() == 4
+        assert_same(hip.download(ldr=False)[0], want, "grid10k progressive with pipelining requested")
+    finally:
+        hip.set_frame_pipelining(0)
+
+
 # ------------------------------------------------------------------- sampler variants (SURVEY.md §8f N3)
 @pytest.mark.parametrize("flags", [1, 2, 3], ids=["cosine-hemisphere", "sqrt-disk", "cosine+sqrt-disk"])
 def test_sampler_variants_device_vs_oracle(hip, oracle, scenes_mod, flags):
@@ -887,6 +949,22 @@ def test_cli_writes_the_same_ppm(hip, oracle, scenes_mod, tmp_path):
     assert data.startswith(b"P6\n200 100\n255\n")
     g = np.load(os.path.join(GOLDEN, "c1_three_200x100_spp1_d8.npz"))
     assert data[len(b"P6\n200 100\n255\n"):] == g["ldr"].tobytes()
+
+
+def test_cli_progressive_frames_with_pipelining_write_the_one_shot_ppm(hip, tmp_path):
+    """The headless app in the reference's mode (one sample per frame, app.cpp:56-76) with frames in flight: same PPM as
+    the one-shot run."""
+    import subprocess
+    from conftest import ROOT
+    cli = os.path.join(ROOT, "cpuraytracer_amd", "lib", "spheres")
+    outs = []
+    for extra in (["--frame-spp", "24"], ["--frame-spp", "1", "--pipeline", "6"]):
+        out = str(tmp_path / ("p%d.ppm" % len(outs)))
+        p = subprocess.run([cli, "--scene", "cover", "--width", "240", "--height", "160", "--spp", "24", "--out", out, "--quiet"] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and len(outs[0]) == len(b"P6\n240 160\n255\n") + 240 * 160 * 3
 
 
 def test_cli_multi_gpu_driver_with_rccl_gather(hip, tmp_path):
