@@ -539,11 +539,33 @@ static TraceVariant ChooseVariant(const rt_ctx* ctx, const rtd::TraceParams& tp)
     return V;
 }
 
+// The queue of fresh paths (rt_params.h): the first static_blocks blocks of every launched wave are static, the remaining
+// paths are cut into eight shards of whole blocks.
+static rtd::ShardStarts QueueShards(rtd::TraceParams& tp, uint32_t wavesLaunched, uint32_t queueBlock, uint32_t staticBlocks) {
+    rtd::ShardStarts st{};
+    tp.queue_block = queueBlock;
+    tp.static_blocks = staticBlocks;
+    const uint64_t total = tp.total_paths, qb = queueBlock;
+    uint64_t begin = (uint64_t)wavesLaunched * qb * staticBlocks;
+    if (begin > total) begin = total;
+    const uint64_t blocks = (total - begin + qb - 1) / qb;
+    uint64_t at = begin;
+    for (uint32_t k = 0; k < rtd::kQueueShards; ++k) {
+        const uint64_t nb = blocks / rtd::kQueueShards + (k < blocks % rtd::kQueueShards ? 1 : 0);
+        uint64_t end = at + nb * qb;
+        if (end > total) end = total;
+        st.begin[k] = tp.shard_begin[k] = (uint32_t)at;
+        tp.shard_end[k] = (uint32_t)end;
+        at = end;
+    }
+    return st;
+}
+
 // Launch the megakernel over total paths described by tp.  carryMode 0: ordinary launch.  1: probe -- RT_OK iff this scene
 // and these settings get the kernel variant that implements frame pipelining (nothing is launched).  2: launch that variant
 // (tp.ctl etc. filled by the caller; the queue cursor lives in tp.ctl and is reset by the preparation kernel).
 static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
-    if (carryMode == 0) RT_HIP(hipMemsetAsync(ctx->queue.ptr, 0, sizeof(uint32_t), ctx->stream));
+    tp.shard_heads = ctx->queue.ptr;
     tp.mats_in_lds = ctx->matsInLds ? 1u : 0u;
     const size_t lds = LdsBytesFor(tp.n, tp.n_padded, ctx->matsInLds);
     if (tp.n_padded >= 65536) return Fail(RT_ERR_INVALID_ARG, "scenes beyond 65,000 spheres are not supported by the 16-bit candidate lists");
@@ -555,6 +577,13 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     if (blocks > maxBlocks) blocks = maxBlocks;
     if (blocks == 0) blocks = 1;
     if (carryMode == 2) blocks = maxBlocks;  // carried paths may outnumber the fresh ones (a flush has none)
+    if (carryMode == 0) {
+        // queue cursors for this launch (the pipelined path sets them in its preparation kernel)
+        const rtd::ShardStarts st = QueueShards(tp, blocks * wavesPerBlock, rtd::kQueueBlock, 1u);
+        hipLaunchKernelGGL(rtd::rt_raygen_tables_kernel, dim3(1), dim3(64), 0, ctx->stream, (float2*)nullptr, 0u, 0u, (float2*)nullptr, 0u, 0u, 0u,
+                           ctx->queue.ptr, st, (rtd::FrameCtl*)nullptr);
+        RT_HIP(hipGetLastError());
+    }
     // dynamic LDS: per-wave candidate regions + the scene tables when they fit + the filter operand image
     const TraceVariant V = ChooseVariant(ctx, tp);
     const bool tree = V.tree, flat = V.flat, ldsTables = V.ldsTables;
@@ -630,27 +659,11 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
 // trace kernel, the commit kernel.  Nothing here waits for the device.
 static void PipelineDrop(rt_ctx* ctx) { ctx->pipeOpen = false; }  // carried paths and uncommitted regions are abandoned
 static uint32_t PipelineWaves(const rt_ctx* ctx) { return (uint32_t)ctx->cuCount * ctx->blocksPerCu * (ctx->blockThreads / 64); }
-// The first static_blocks blocks of every wave are static; the remaining paths of the call are cut into eight shards.
 static rtd::ShardStarts PipelineShards(const rt_ctx* ctx, rtd::TraceParams& tp) {
-    rtd::ShardStarts st{};
-    const uint64_t total = tp.total_paths;
-    tp.static_blocks = EnvU32("RT_PIPE_STATIC_BLOCKS", 1);  // measured (tools/progressive_frames.py): 128 x 1 beats 64 x 2, 128 x 0, 192 x 1
-    tp.queue_block = EnvU32("RT_PIPE_QUEUE_BLOCK", rtd::kCarryQueueBlock) / 64u * 64u;
-    if (tp.queue_block == 0) tp.queue_block = 64;
-    const uint64_t qb = tp.queue_block;
-    uint64_t begin = (uint64_t)PipelineWaves(ctx) * qb * tp.static_blocks;
-    if (begin > total) begin = total;
-    const uint64_t blocks = (total - begin + qb - 1) / qb;
-    uint64_t at = begin;
-    for (uint32_t k = 0; k < rtd::kQueueShards; ++k) {
-        const uint64_t nb = blocks / rtd::kQueueShards + (k < blocks % rtd::kQueueShards ? 1 : 0);
-        uint64_t end = at + nb * qb;
-        if (end > total) end = total;
-        st.begin[k] = tp.shard_begin[k] = (uint32_t)at;
-        tp.shard_end[k] = (uint32_t)end;
-        at = end;
-    }
-    return st;
+    // measured (tools/progressive_frames.py, 1-spp frames): 128-path blocks x 1 static beat 64 x 2, 128 x 0, 192 x 1, 256 x 0
+    uint32_t qb = EnvU32("RT_PIPE_QUEUE_BLOCK", rtd::kCarryQueueBlock) / 64u * 64u;
+    if (qb == 0) qb = 64;
+    return QueueShards(tp, PipelineWaves(ctx), qb, EnvU32("RT_PIPE_STATIC_BLOCKS", 1));
 }
 
 static int PipelineTraceAndCommit(rt_ctx* ctx, rtd::TraceParams& tp, uint32_t npix, bool carry) {
@@ -663,7 +676,6 @@ static int PipelineTraceAndCommit(rt_ctx* ctx, rtd::TraceParams& tp, uint32_t np
     tp.region_seq = ctx->pipeSeq;
     tp.max_carry_age = ctx->pipeDepth;
     tp.min_iters = EnvU32("RT_PIPE_MIN_ITERS", 8);
-    tp.queue_head = nullptr;  // the carrying kernel uses the sharded cursors in tp.ctl
     tp.counters = ctx->counters.ptr;
     int rc = LaunchTrace(ctx, tp, 2);
     if (rc != RT_OK) return rc;
@@ -682,7 +694,7 @@ static int PipelineFlush(rt_ctx* ctx) {
     rtd::TraceParams tp = ctx->base;
     tp.total_paths = 0;  // nothing fresh: only the carried paths
     hipLaunchKernelGGL(rtd::rt_raygen_tables_kernel, dim3(1), dim3(256), 0, ctx->stream, (float2*)nullptr, 0u, 0u, (float2*)nullptr, 0u, 0u,
-                       ctx->sampler, ctx->ctl.ptr, PipelineShards(ctx, tp));
+                       ctx->sampler, ctx->queue.ptr, PipelineShards(ctx, tp), ctx->ctl.ptr);
     RT_HIP(hipGetLastError());
     tp.W = ctx->W;
     tp.H = ctx->H;
@@ -762,7 +774,7 @@ static int PipelineRender(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uin
     tp.lens_k0 = k0;
     const uint32_t nmax = spp > nLens ? spp : nLens;
     hipLaunchKernelGGL(rtd::rt_raygen_tables_kernel, dim3((nmax + 255) / 256), dim3(256), 0, ctx->stream, ctx->jitterTab.ptr, s0, spp,
-                       ctx->lensTab.ptr, k0, nLens, ctx->sampler, ctx->ctl.ptr, PipelineShards(ctx, tp));
+                       ctx->lensTab.ptr, k0, nLens, ctx->sampler, ctx->queue.ptr, PipelineShards(ctx, tp), ctx->ctl.ptr);
     RT_HIP(hipGetLastError());
     return PipelineTraceAndCommit(ctx, tp, npix, true);
 }
@@ -822,7 +834,7 @@ int rt_create(int device_ordinal, rt_ctx** out) {
     ctx->forceGlobal = EnvU32("RT_FORCE_GLOBAL_TABLES", 0) != 0;
     ctx->blockThreads = EnvU32("RT_BLOCK_THREADS", ctx->useMfma ? 1024 : 256);
     if (ctx->blockThreads != 256 && ctx->blockThreads != 512 && ctx->blockThreads != 1024) ctx->blockThreads = 256;
-    int rc = ctx->queue.Reserve(1);
+    int rc = ctx->queue.Reserve(rtd::kQueueShards * 32);  // eight queue cursors, 128 bytes apart
     if (rc == RT_OK) rc = ctx->counters.Reserve(2);
     if (rc != RT_OK) return rc;
     {
@@ -1117,7 +1129,6 @@ int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, ui
             tp.path_list = nullptr;
             tp.samples = ctx->samples.ptr;
             tp.trav_out = nullptr;
-            tp.queue_head = ctx->queue.ptr;
             tp.counters = ctx->counters.ptr;
             // ray-generation tables for this pass: s in [s, s+spp), k = s+i+j over the strip's rows
             const uint32_t k0 = s + rs.first_row;
@@ -1366,7 +1377,6 @@ int rt_unit_trace(rt_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* ijs, uint
     tp.lens_tab = nullptr;
     tp.samples = dOut.p;
     tp.trav_out = dTrav.p;
-    tp.queue_head = ctx->queue.ptr;
     tp.counters = ctx->counters.ptr;
     int rc = LaunchTrace(ctx, tp);
     if (rc != RT_OK) return rc;

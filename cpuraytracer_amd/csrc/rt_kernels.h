@@ -180,6 +180,27 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
     }
 }
 
+// Next block of fresh paths for this wave (rt_params.h, "the queue of fresh paths"); false when every shard is empty.
+RT_DEV bool claim_block(const TraceParams& p, uint32_t lane, uint32_t qb, uint32_t& blkNext, uint32_t& blkEnd) {
+    for (uint32_t a = 0; a < kQueueShards; ++a) {
+        const uint32_t k = (blockIdx.x + a) & (kQueueShards - 1u);
+        uint32_t* head = p.shard_heads + 32u * k;
+        const uint32_t endK = p.shard_end[k];
+        uint32_t b = 0;
+        if (lane == 0) b = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        if (b >= endK) continue;
+        if (lane == 0) b = atomicAdd(head, qb);
+        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        if (b < endK) {
+            blkNext = b;
+            blkEnd = (b + qb) < endK ? (b + qb) : endK;
+            return true;
+        }
+    }
+    return false;
+}
+
 // ============================================================================ megakernel
 // Persistent threads: every wave loops { refill idle lanes from the queue; one list scan for all
 // lanes; per-lane state transition } until the queue is empty and all its lanes are idle.  Waves
@@ -251,7 +272,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     uint32_t carried = 0;  // kCarry: paths this wave carries out (wave-uniform)
     uint32_t itersHere = 0;  // kCarry: iterations of this wave in this launch
     const uint32_t gwave = blockIdx.x * (kThreads / kWaveSize) + threadIdx.x / kWaveSize;  // this wave's index in the grid
-    const uint32_t kBlk = kCarry ? p.queue_block : kQueueBlock;  // paths per queue block
+    const uint32_t kBlk = p.queue_block;  // paths per queue block (a multiple of 64)
     bool contAfterShadow = false, pathScattered = false;
     uint32_t nTrav = 0, nSeg = 0;
 
@@ -281,9 +302,11 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
             contAfterShadow = (fl & 4u) != 0u;
             pathScattered = (fl & 8u) != 0u;
         }
-        // ... and its first block of fresh paths is static too: block `gwave`; the shared cursor starts behind those.
-        // Blocks are half the usual size here: a wave can only start paths as lanes fall idle, so a wave whose lanes are held
-        // by long paths should own little unstarted work when the queue runs dry (it must start all of it before it may leave).
+    }
+    {
+        // the wave's first block(s) of fresh paths are static: block `gwave`; the shards start behind those.  (The carrying
+        // kernel uses half-size blocks: a wave can only start paths as lanes fall idle, so a wave whose lanes are held by long
+        // paths should own little unstarted work when the queue runs dry -- it must start all of it before it may leave.)
         const uint32_t b0 = gwave * (kBlk * p.static_blocks);
         blkNext = b0 < p.total_paths ? b0 : p.total_paths;
         blkEnd = (b0 + kBlk * p.static_blocks) < p.total_paths ? (b0 + kBlk * p.static_blocks) : p.total_paths;
@@ -309,40 +332,9 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                 if (cachePos == cacheCnt) {
                     if (queueEmpty) break;
                     if (blkNext == blkEnd) {
-                        uint32_t b = 0;
-                        if (kCarry) {
-                            // sharded queue: the workgroup's own shard first, then the others.  Look before claiming: thousands
-                            // of waves find a shard empty within microseconds of each other, and a load is served from L2
-                            // while same-address atomics queue up one behind the other.
-                            bool got = false;
-                            for (uint32_t a = 0; a < kQueueShards && !got; ++a) {
-                                const uint32_t k = (blockIdx.x + a) & (kQueueShards - 1u);
-                                uint32_t* head = &p.ctl->shard_head[k][0];
-                                const uint32_t endK = p.shard_end[k];
-                                if (lane == 0) b = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                                if (b >= endK) continue;
-                                if (lane == 0) b = atomicAdd(head, kBlk);
-                                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                                if (b < endK) {
-                                    blkNext = b;
-                                    blkEnd = (b + kBlk) < endK ? (b + kBlk) : endK;
-                                    got = true;
-                                }
-                            }
-                            if (!got) {
-                                queueEmpty = true;
-                                break;
-                            }
-                        } else {
-                            if (lane == 0) b = atomicAdd(p.queue_head, kBlk);
-                            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                            blkNext = b < p.total_paths ? b : p.total_paths;
-                            blkEnd = (b + kBlk) < p.total_paths ? (b + kBlk) : p.total_paths;
-                            if (b >= p.total_paths) {
-                                queueEmpty = true;
-                                break;
-                            }
+                        if (!claim_block(p, lane, kBlk, blkNext, blkEnd)) {
+                            queueEmpty = true;
+                            break;
                         }
                     }
                     const uint32_t nGen = (blkEnd - blkNext) < (uint32_t)kWaveSize ? (blkEnd - blkNext) : (uint32_t)kWaveSize;
@@ -387,12 +379,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         } else {
             while (idleMask != 0ull && !queueEmpty) {
                 if (blkNext == blkEnd) {
-                    uint32_t b = 0;
-                    if (lane == 0) b = atomicAdd(p.queue_head, kQueueBlock);
-                    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                    blkNext = b < p.total_paths ? b : p.total_paths;
-                    blkEnd = (b + kQueueBlock) < p.total_paths ? (b + kQueueBlock) : p.total_paths;
-                    if (b >= p.total_paths) {
+                    if (!claim_block(p, lane, kBlk, blkNext, blkEnd)) {
                         queueEmpty = true;
                         break;
                     }
@@ -642,15 +629,12 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
 
 // ============================================================ ray-generation tables (A1, A9)
 // jitter[k] = Halton2D(s0+k; 2,3) (spheres-app.cpp:140), lens[k] = HaltonSampleDisk(k0+k; 4,5) (:152)
-// Frame pipelining: the first threads also reset the cursors of the pipeline's control block for the trace kernel that follows.
-struct ShardStarts {
-    uint32_t begin[kQueueShards];
-};
+// The first threads also set the queue cursors (and, frame pipelining, the control block) for the trace kernel that follows.
 __global__ void __launch_bounds__(256) rt_raygen_tables_kernel(float2* jitter, uint32_t s0, uint32_t nJitter, float2* lens, uint32_t k0,
-                                                               uint32_t nLens, uint32_t sampler, FrameCtl* ctl = nullptr,
-                                                               ShardStarts shards = ShardStarts{}) {
+                                                               uint32_t nLens, uint32_t sampler, uint32_t* shardHeads = nullptr,
+                                                               ShardStarts shards = ShardStarts{}, FrameCtl* ctl = nullptr) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ctl && k < kQueueShards) ctl->shard_head[k][0] = shards.begin[k];
+    if (shardHeads && k < kQueueShards) shardHeads[32u * k] = shards.begin[k];
     if (ctl && k == 0) ctl->oldest_open = 0xffffffffu;
     if (k < nJitter) jitter[k] = make_float2(halton(s0 + k, 2), halton(s0 + k, 3));
     if (k < nLens) {

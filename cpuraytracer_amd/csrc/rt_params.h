@@ -44,6 +44,16 @@ constexpr uint32_t kCarryQueueBlock = 128; // ... in the frame-pipelining kernel
 // frame j ends as soon as the fresh queue is empty and CARRIES its unfinished paths (80-byte entries) into the kernel of
 // frame j+1.  Each rt_render call owns one region of a ring of sample buffers; regions are added to the HDR strip strictly in
 // call order, and only once no carried path belongs to them (FrameCtl::oldest_open).
+// The queue of fresh paths (every trace kernel): a wave owns TraceParams::static_blocks blocks statically (block index =
+// wave index: no claim, and no rush of 4,096 simultaneous atomics when the kernel starts); the rest of the launch's paths
+// sits in eight shards (a workgroup prefers shard blockIdx & 7 -- workgroups are dealt round-robin over the 8 XCDs -- and
+// steals from the others when its own is dry) whose cursors are 128 bytes apart, and a wave LOOKS at a cursor before it
+// claims: same-line atomics are served one behind the other (~11 ns each), loads are not.
+constexpr uint32_t kQueueShards = 8;
+struct ShardStarts {
+    uint32_t begin[kQueueShards];
+};
+
 struct ContEntry {
     float4 a, b, c, d, e;  // ro.xyz rd.x | rd.yz thr.xy | thr.z rad.xyz | xoshiro s0..s3 | slot, depth, region sequence & 255, traversals
     float4 f, g;           // a lane waiting for its shadow scan (far hit point): pend.xyz nextDir.x | nextDir.yz, state and flags, -
@@ -52,12 +62,7 @@ struct ContEntry {
 // the outgoing buffer and n to the outgoing count array, and wave w of the next kernel restores exactly those -- no cursor,
 // no atomics.  (A first version claimed entries, fresh blocks and output slots with atomics on one control block: ~27,000
 // same-line atomics per 1-spp frame, which one L2 channel serialises at ~11 ns each -- 0.3 ms per frame.)
-// Fresh paths: every wave owns TraceParams::static_blocks blocks of 64 statically; the rest of the call's paths sits in eight
-// queue shards (one per XCD, a workgroup prefers shard blockIdx & 7 and steals from the others when its own is dry) whose
-// cursors are 128 bytes apart: ~7,000 claims per 1-spp frame spread over eight L2 lines instead of one.
-constexpr uint32_t kQueueShards = 8;
 struct FrameCtl {            // device control block of one context's pipeline
-    uint32_t shard_head[kQueueShards][32];  // [k][0]: cursor of queue shard k (reset before every trace kernel)
     uint32_t oldest_open;    // min region sequence among the paths carried out of the last trace kernel (0xffffffff: none)
     uint32_t committed_seq;  // regions with sequence <= this are in the HDR strip
     uint32_t committed_samples;  // samples per pixel in the HDR strip
@@ -129,7 +134,7 @@ struct TraceParams {
     uint32_t shard_begin[kQueueShards], shard_end[kQueueShards];  // path ranges of the queue shards (multiples of 64)
     uint32_t sample_base;       // first 12-byte slot of this call's region in the sample ring (0 without pipelining)
     uint32_t ray_cache_off16;  // float4 offset of the per-wave prepared-path caches in dynamic LDS, 0 = no cache
-    uint32_t* queue_head;       // global work counter, zeroed before launch
+    uint32_t* shard_heads;      // [kQueueShards][32]: [k][0] = cursor of queue shard k (set to shard_begin[k] before launch)
     unsigned long long* counters;  // [0] traversals, [1] segments
 };
 
