@@ -626,9 +626,9 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     } while (0)
 #define RT_LAUNCH(LDS, T, M)                                                                        \
     do {                                                                                            \
-        if ((M) == 1 && hitLds) {                                                                   \
-            if (tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<LDS, T, M, true, (M) == 1>));  \
-            else RT_LAUNCH_K((rtd::rt_trace_kernel<LDS, T, M, false, (M) == 1>));                    \
+        if (((M) == 1 && hitLds) || ((M) == 2 && tp.tree_in_lds)) {                                 \
+            if (tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<LDS, T, M, true, (M) != 0>));  \
+            else RT_LAUNCH_K((rtd::rt_trace_kernel<LDS, T, M, false, (M) != 0>));                    \
         } else {                                                                                    \
             if (tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<LDS, T, M, true, false>));    \
             else RT_LAUNCH_K((rtd::rt_trace_kernel<LDS, T, M, false, false>));                      \

@@ -94,8 +94,8 @@ struct SceneTabs {
 // LDS to tabBase (16-byte aligned pieces: scan | one-sphere bounds (flat matrix-core scan only) | orig | materials (48 B =
 // 3 float4) | radii | filter operands | shadow index; tree mode: operands | all levels of bounds) and build the filter's
 // operand image.  Every thread of the workgroup must call it.
-// kHitLds (flat matrix-core variant only): the material table and the shadow index are in LDS too, and their pointers
-// are assigned unconditionally so that the compiler can prove the address space -- a pointer that is LDS or global
+// kHitLds: flat matrix-core variant -- the material table and the shadow index are in LDS too; hierarchy variant -- all
+// levels of bounds are in LDS.  Their pointers are assigned unconditionally so that the compiler can prove the address space -- a pointer that is LDS or global
 // depending on a run-time flag becomes a FLAT load, and every flat load waits for vmcnt(0) AND lgkmcnt(0), i.e. also
 // for the previous iteration's sample stores.  The host launches it only when p.mats_in_lds and (p.sg_in_lds or no index).
 template <bool kLds, int kScan, bool kHitLds = false>
@@ -170,7 +170,7 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
         float* ldsOps = reinterpret_cast<float*>(tabBase);
         build_mfma_operands(p.tree + p.level_off[topLevel], nTop, nTiles, ldsOps, threadIdx.x, blockDim.x);
         T.ops = ldsOps;
-        if (p.tree_in_lds) {
+        if (kHitLds) {  // hierarchy scan: every level of bounds is in LDS (typed pointer: the descent's node reads are ds_read, not flat)
             float4* ldsTree = reinterpret_cast<float4*>(ldsOps + (size_t)nTiles * kOpsPerTile);
             const uint32_t nNodes = p.level_off[topLevel] + nTop;
             for (uint32_t k = threadIdx.x; k < nNodes; k += blockDim.x) ldsTree[k] = p.tree[k];
@@ -215,6 +215,7 @@ template <bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds = false,
 __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams p) {
     constexpr bool kMfma = kScan != 0;
     static_assert(!kCarry || (kCache && kHitLds && kScan == 1), "frame pipelining is built for the flat LDS variant only");
+    static_assert(!kHitLds || kScan != 0, "kHitLds belongs to the matrix-core variants");
 #ifdef RT_TIMELINE
     const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz; diagnostic build only
 #endif
