@@ -253,7 +253,7 @@ def main():
                                    "rows sharded cyclically over %d GPU(s) in 4-row blocks, RCCL gather of strips to rank 0"
                                    % (cfg["scene"], n_spheres, SCENE_SEED, W_IMG, H_IMG, spp, DEPTH,
                                       (" aperture=%.1f" % cfg["aperture"]) if cfg["aperture"] >= 0 else "", RENDER_SEED, N),
-                       "name": args.config, "spp": spp, "spp_per_gpu": SPP_PER_GPU, "samples_per_step": total_samples,
+                       "name": args.config, "n_spheres": n_spheres, "spp": spp, "spp_per_gpu": SPP_PER_GPU, "samples_per_step": total_samples,
                        "traversals_per_sample": avg_trav / (W_IMG * rows * spp), "passes": st_last.passes},
             "roofline": roofline,
             "cull_factor": cull,

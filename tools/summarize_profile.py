@@ -76,6 +76,19 @@ if os.path.exists(prev):
     except Exception:
         pass
 json.dump(out, open(prev, "w"), indent=1)
+# the bench line of this profile run was printed before this summary existed: fill in its roofline object now, from the
+# live launch duration that line measured and the counters of the PMC passes of the same run
+for tag in ("_bench_line", "_bench_under_rocprof"):
+    path = prefix + tag + suffix + ".json"
+    b = json.load(open(path))
+    if b and b.get("roofline", {}).get("frac") is None:
+        cfg = _bench.CONFIGS[b["config"].get("name", "c2")]
+        n_sph = b["config"].get("n_spheres") or int(b["config"]["workload"].split("(")[1].split(" ")[0])
+        trav = b["config"]["traversals_per_sample"] * b["config"]["samples_per_step"]
+        rl, cull = _bench.roofline_object(cfg, b["roofline"]["kernel"], b["roofline"]["launch_ms"], trav, n_sph, out["kernel_sources_sha256"])
+        rl["filled_in_by"] = "tools/summarize_profile.py (the PMC passes ran after this line was printed)"
+        b["roofline"], b["cull_factor"] = rl, cull
+        json.dump(b, open(path, "w"), indent=1)
 json.dump({"hbm_bytes_per_launch": fetch_b + write_b, "source": os.path.basename(prev) + " (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; FETCH doubled per the gfx950 correction)"},
           open(prefix + "_hbm_traffic" + suffix + ".json", "w"))
 print(json.dumps(derived, indent=1))
