@@ -1265,7 +1265,7 @@ int rt_unit_halton(rt_ctx* ctx, const uint32_t* index, uint32_t base, uint32_t n
 }
 
 int rt_unit_math(rt_ctx* ctx, uint32_t op, const float* x, const float* y, uint32_t n, float* out) {
-    if (!ctx || !x || !out || op > 3) return Fail(RT_ERR_INVALID_ARG, "rt_unit_math: invalid argument");
+    if (!ctx || !x || !out || op > 6) return Fail(RT_ERR_INVALID_ARG, "rt_unit_math: invalid argument");
     if (n == 0) return RT_OK;
     RT_HIP(hipSetDevice(ctx->device));
     TmpDev<float> dX, dY, dOut;

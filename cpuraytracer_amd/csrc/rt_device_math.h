@@ -44,6 +44,51 @@ RT_DEV float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 
 RT_DEV float sat1(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }  // XMVectorSaturate per lane
 
+// ---------------------------------------------------------------- correctly rounded division, cheaper
+// x / b as the compiler expands it (v_div_scale x2, v_rcp, five fma, v_div_fmas, v_div_fixup) is 11 VALU operations, and the
+// hit processing divides ~20 times per hit, mostly several numerators by one denominator.  Markstein's theorem: with
+// y = RN(1/b) and q0 = RN(x y), the residual r = x - b q0 is exact in an fma and q1 = RN(q0 + r y) = RN(x / b), provided
+// nothing leaves the normal range.  recip_rn refines the hardware's 1-ulp v_rcp_f32 with one Newton step (3 operations);
+// div_rn is mul + fma + fma + a sign transfer (x = -0 would otherwise give +0).  Preconditions, checked by the callers
+// with div_exponents_ok(): b in [2^-20, 2^100] and every numerator zero or with x / b >= 2^-80 in magnitude (then
+// |x| >= 2^-100, the quotient is normal and r, a multiple of 2^(e_x - 46), is representable).  Outside them the plain
+// division runs.  tests/test_gpu_parity.py::test_markstein_division_is_ieee_division runs both on the device for all 2^23
+// significands of b against 1/b and for millions of quotients incl. the guard's edges; a CPU brute force over 1.9e10
+// (x, b) pairs of the same sequence found no mismatch.  Host builds (the C++ host mirror) use the plain division.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_NO_MARKSTEIN)
+#define RT_MARKSTEIN 1
+RT_DEV float recip_rn(float b) {
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+RT_DEV float div_rn(float x, float b, float y) {
+    const float q0 = x * y;
+    const float r = __builtin_fmaf(-b, q0, x);
+    return __builtin_copysignf(__builtin_fmaf(r, y, q0), x);  // b > 0 at every call site
+}
+RT_DEV int float_exponent(float x) { return __builtin_amdgcn_frexp_expf(x); }  // 0 for x == 0, else floor(log2|x|) + 1
+// one denominator, three numerators (a zero numerator has exponent 0: fine unless b > 2^80, where the slow path is taken)
+RT_DEV bool div_exponents_ok(float x0, float x1, float x2, float b) {
+    const int e0 = float_exponent(x0), e1 = float_exponent(x1), e2 = float_exponent(x2), eb = float_exponent(b);
+    const int m = e0 < e1 ? (e0 < e2 ? e0 : e2) : (e1 < e2 ? e1 : e2);
+    return (unsigned)(eb + 19) <= 119u && m - eb >= -80;
+}
+#else
+#define RT_MARKSTEIN 0
+#endif
+
+// v / b per component (true divide), b > 0.
+RT_DEV V3 div3(V3 v, float b) {
+#if RT_MARKSTEIN
+    if (__builtin_expect(div_exponents_ok(v.x, v.y, v.z, b), 1)) {
+        const float y = recip_rn(b);
+        return {div_rn(v.x, b, y), div_rn(v.y, b, y), div_rn(v.z, b, y)};
+    }
+#endif
+    return {v.x / b, v.y / b, v.z / b};
+}
+
 // XMVector3Normalize (SSE2): zero length -> 0, infinite length -> QNaN, else true divide.
 RT_DEV V3 normalize3(V3 v) {
     const float lenSq = dot3(v, v);
@@ -53,7 +98,7 @@ RT_DEV V3 normalize3(V3 v) {
         return {q, q, q};
     }
     if (len == 0.f) return {0.f, 0.f, 0.f};
-    return {v.x / len, v.y / len, v.z / len};
+    return div3(v, len);
 }
 
 // XMVector3Cross

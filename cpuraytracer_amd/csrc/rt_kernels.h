@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                 const Mat m = load_material(matTab, idx);
                 const V3 center = v3(S.x, S.y, S.z);
                 const V3 pos = tmin * rd + ro;          // XMVectorMultiplyAdd(t, dir, origin), ray-tracing.cpp:57
-                const V3 nrm = (pos - center) / radius;  // ray-tracing.cpp:58
+                const V3 nrm = div3(pos - center, radius);  // ray-tracing.cpp:58 (true divide; radius > 0)
                 V3 atten, local, localOcc, tex;
                 RT_STAMP(th0);
                 const bool scattered = scatter_only(m, rd, nrm, draws, atten, nextDir, tex, mt, K.sampler);  // Scatter first: it draws (spheres-app.cpp:246)
@@ -763,6 +763,17 @@ __global__ void k_unit_math(uint32_t op, const float* x, const float* y, uint32_
     else if (op == 1) r = rt_cosf(x[k]);
     else if (op == 2) r = rt_powf(x[k], y[k]);
     else if (op == 3) r = rt_tanf(x[k]);
+#if RT_MARKSTEIN
+    else if (op == 4) r = recip_rn(x[k]);  // must equal 1.0f / x for normal x in [2^-100, 2^100]
+    else if (op == 5) {                      // the quotient the hit processing forms (guarded): must equal x / y
+        const V3 q = div3(v3(x[k], 0.f, -x[k]), y[k]);
+        r = q.x;
+    }
+#else
+    else if (op == 4) r = 1.0f / x[k];
+    else if (op == 5) r = x[k] / y[k];
+#endif
+    else if (op == 6) r = x[k] / y[k];      // the compiler's IEEE division, on the device
     out[k] = r;
 }
 __global__ void k_unit_primary(const TraceParams p, const uint32_t* ijs, uint32_t n, float* out) {

@@ -183,7 +183,22 @@ RT_DEV bool scatter_and_shade(const P& p, const Mat& m, V3 rd, V3 pos, V3 nrm, D
 // 2|c|^2 + r^2); the footprints are inflated for that with |p| <= P0 (and for the rounding of the
 // projection), so inside that radius the answer is exactly the reference's.  Points farther out fall
 // back to the shadow scan.
-RT_DEV bool sphere_any_hit(const float4 S, V3 o, V3 d, float a) {
+// num / a > 0.001 (ray-tracing.cpp:56,69 with the bias test of :52) for the shadow rays, whose a = |L|^2 is the same for
+// all of them: ya = recip_rn(a) once per kernel, then Markstein's correction (rt_device_math.h) instead of an 11-operation
+// division.  Only the COMPARISON matters: for |num| < 2^100 and a in [2^-19, 2^100] the quotient is exact wherever it is
+// normal -- in particular around 0.001 -- and where it underflows both forms are far below the bias.  aOk == false (or a
+// huge numerator) takes the plain division.
+RT_DEV bool root_exceeds_bias(float num, float a, float ya, bool aOk) {
+#if RT_MARKSTEIN
+    if (__builtin_expect(aOk && __builtin_fabsf(num) < 0x1p100f, 1)) {
+        const float q0 = num * ya;
+        const float r = __builtin_fmaf(-a, q0, num);
+        return __builtin_fmaf(r, ya, q0) > 0.001f;
+    }
+#endif
+    return num / a > 0.001f;
+}
+RT_DEV bool sphere_any_hit(const float4 S, V3 o, V3 d, float a, float ya, bool aOk) {
     const float ocx = o.x - S.x;
     const float ocy = o.y - S.y;
     const float ocz = o.z - S.z;
@@ -192,8 +207,8 @@ RT_DEV bool sphere_any_hit(const float4 S, V3 o, V3 d, float a) {
     const float disc = b * b - a * cc;
     if (disc > 0.f) {  // ray-tracing.cpp:54-71
         const float sq = __builtin_sqrtf(disc);
-        if ((-b - sq) / a > 0.001f) return true;
-        if ((-b + sq) / a > 0.001f) return true;
+        if (root_exceeds_bias(-b - sq, a, ya, aOk)) return true;
+        if (root_exceeds_bias(-b + sq, a, ya, aOk)) return true;
     }
     return false;
 }
@@ -207,6 +222,13 @@ RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint1
     bool occluded = false;
     unsigned long long queue = 0ull;
     uint32_t nq = 0;
+#if RT_MARKSTEIN
+    const bool aOk = (unsigned)(float_exponent(aL) + 19) <= 119u;  // wave-uniform, loop-invariant: a of the sun direction
+    const float yaL = recip_rn(aL);
+#else
+    const bool aOk = false;
+    const float yaL = 0.f;
+#endif
 #define RT_CONSIDER(ID)                                                              \
     {                                                                                \
         const uint32_t id_ = (ID);                                                   \
@@ -222,7 +244,7 @@ RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint1
                 queue = (queue << 16) | (unsigned long long)id_;                     \
                 ++nq;                                                                \
             } else {                                                                 \
-                occluded = occluded || sphere_any_hit(S, pos, L, aL); /* queue full (rare): evaluate now */ \
+                occluded = occluded || sphere_any_hit(S, pos, L, aL, yaL, aOk); /* queue full (rare): evaluate now */ \
             }                                                                        \
         }                                                                            \
     }
@@ -240,7 +262,7 @@ RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint1
         const uint32_t id = (uint32_t)(queue & 0xffffull);
         queue >>= 16;
         --nq;
-        occluded = sphere_any_hit(tab[id], pos, L, aL);
+        occluded = sphere_any_hit(tab[id], pos, L, aL, yaL, aOk);
     }
     return occluded;
 }

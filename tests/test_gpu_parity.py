@@ -71,6 +71,33 @@ def test_elementary_functions_device_vs_oracle(hip, oracle):
         assert_same(hip.unit_math(2, xb, yy), oracle.math_array(2, xb, yy), "pow y=%g" % y)
 
 
+def test_markstein_division_is_ieee_division(hip):
+    """The hit processing divides with Markstein's correction on a refined hardware reciprocal instead of the compiler's
+    11-operation IEEE sequence (rt_device_math.h).  (a) the refined reciprocal equals 1/b for ALL 2^23 significands, at three
+    exponents; (b) the guarded quotient equals the device's plain division and numpy's on millions of operand pairs over the
+    whole exponent range (the guard's fallback included), signed zeros and the worst-case significands."""
+    sig = np.arange(1 << 23, dtype=np.uint32)
+    for e in (27, 127, 227):
+        x = (sig | np.uint32(e << 23)).view(np.float32)
+        assert_same(hip.unit_math(4, x), (np.float32(1.0) / x).astype(np.float32), "refined reciprocal, exponent %d" % (e - 127))
+    rng = np.random.default_rng(3)
+    n = 4_000_000
+    eb = rng.integers(-30, 110, n)
+    ex = eb + rng.integers(-100, 30, n)
+    b = (rng.uniform(1, 2, n) * np.exp2(eb.astype(np.float64))).astype(np.float32)
+    x = (rng.uniform(1, 2, n) * np.exp2(np.clip(ex, -148, 126).astype(np.float64)) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+    x[:1000] = 0.0
+    x[1000:2000] = -0.0
+    got = hip.unit_math(5, x, b)
+    assert_same(got, hip.unit_math(6, x, b), "Markstein quotient vs the device's IEEE division")
+    with np.errstate(over="ignore", under="ignore"):
+        assert_same(got, (x / b).astype(np.float32), "Markstein quotient vs numpy")
+    xs = rng.uniform(-4, 4, 500_000).astype(np.float32)
+    for bits_ in (0x3fffffff, 0x3f800000, 0x3f800001, 0x3ffffffe, 0x3fc00000):
+        bb = np.full_like(xs, np.array([bits_], dtype=np.uint32).view(np.float32)[0])
+        assert_same(hip.unit_math(5, xs, bb), (xs / bb).astype(np.float32), "quotients by significand %#x" % bits_)
+
+
 def test_camera_rays_device_vs_oracle(hip, oracle, scenes_mod):
     rng = np.random.default_rng(2)
     for name, W, H, ap in (("cover", 1200, 800, -1.0), ("cover", 1920, 1080, 2.0), ("three", 200, 100, -1.0)):
