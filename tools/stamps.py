@@ -6,7 +6,8 @@ from cpuraytracer_amd import _capi
 _capi.LIB_PATH = os.path.join(ROOT, "cpuraytracer_amd", "lib", "librt_hip_stamps.so")
 from cpuraytracer_amd import HipRenderer, scenes
 r = HipRenderer(0)
-r.upload(scenes.build_scene("cover", 1, 1200, 800))
+SCENE = sys.argv[1] if len(sys.argv) > 1 else "cover"
+r.upload(scenes.build_scene(SCENE, 1, 1200, 800))
 L = _capi.load()
 out = (C.c_ulonglong * 20)()
 L.rt_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
