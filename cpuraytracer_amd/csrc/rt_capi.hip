@@ -889,6 +889,11 @@ void rt_destroy(rt_ctx* ctx) {
 
 int rt_set_stream(rt_ctx* ctx, void* hip_stream) {
     if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_set_stream: null ctx");
+    {   // frames in flight belong to the old stream: settle them there first
+        RT_HIP(hipSetDevice(ctx->device));
+        const int rcf = PipelineFlush(ctx);
+        if (rcf != RT_OK) return rcf;
+    }
     ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->ownStream;
     return RT_OK;
 }

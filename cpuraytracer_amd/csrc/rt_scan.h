@@ -634,15 +634,23 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
             rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B3, fg, fd, fa, fdO, fcr, fbt), 31);
             const uint32_t m = has ? (~rb & 15u) : 0u;  // bit 3-q = child 4j + q
             if (nExact > kTreeExact - 4u * kWaveSize) drainExact();
-#pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) {
-                const bool hit = ((m >> (3u - q)) & 1u) != 0u;
-                const uint64_t wm = __ballot(hit && internal);
-                const uint64_t em = __ballot(hit && !internal);
-                if (hit && internal) work[nWork + prefix_count(wm)] = r << 20 | (lvl - 1u) << 16 | (4u * j + q);
-                if (hit && !internal) exact[nExact + prefix_count(em)] = r << 16 | (4u * j + q);
-                nWork += (uint32_t)__popcll(wm);
-                nExact += (uint32_t)__popcll(em);
+            {   // one prefix sum per list over the lanes' survivor counts (a lane's survivors all go to the same list), then
+                // every lane appends its own 0..4 entries -- instead of eight ballots and conditional stores per round
+                const uint32_t nh = (uint32_t)__builtin_popcount(m);
+                const uint32_t nW = internal ? nh : 0u, nE = internal ? 0u : nh;
+                const uint32_t inclW = wave_inclusive_sum(nW), inclE = wave_inclusive_sum(nE);
+                const uint32_t totW = (uint32_t)__builtin_amdgcn_readlane((int)inclW, 63);
+                const uint32_t totE = (uint32_t)__builtin_amdgcn_readlane((int)inclE, 63);
+                uint32_t* wp = internal ? work + nWork + (inclW - nW) : exact + nExact + (inclE - nE);
+                const uint32_t tag = internal ? (r << 20 | (lvl - 1u) << 16) : (r << 16);
+                uint32_t mm = m;
+                while (mm != 0u) {
+                    const uint32_t bit = 31u - (uint32_t)__builtin_clz(mm);
+                    mm &= ~(1u << bit);
+                    *wp++ = tag | (4u * j + (3u - bit));
+                }
+                nWork += totW;
+                nExact += totE;
             }
         }
         drainExact();
