@@ -52,17 +52,22 @@ RT_DEV void path_coordinates(const TraceParams& p, uint32_t q, uint32_t& i, uint
         s = p.path_list[3 * q + 2];
         slot = q;
     } else {
-        // work order = storage order = [tile of 64 local pixels][sample of the pass][pixel in tile] (the last tile is as
-        // wide as the pixels left): a wave's block of 256 consecutive work-items is four sample planes of one tile, so
-        // its 12-byte results fill whole cache lines, and rt_accumulate_kernel reads 768 contiguous bytes per plane
+        // storage order = [tile of 64 local pixels][sample of the pass][pixel in tile] (the last tile is as wide as the
+        // pixels left): a wave's block of 256 consecutive work-items is four sample planes of one tile, so its 12-byte
+        // results fill whole cache lines, and rt_accumulate_kernel reads 768 contiguous bytes per plane.  The WORK order
+        // is the same with the full tiles permuted by tile_order (expensive tiles first, sky last: rt_tile_order_kernel),
+        // so that the 51-segment paths are not the last ones a launch starts; the partial tile stays last.
         const uint32_t tileSpan = 64u * p.spp_pass;
         const uint32_t nFull = p.npix_local >> 6;
-        const uint32_t tile = q / tileSpan;
+        const uint32_t tileW = q / tileSpan;
         uint32_t pl, k;
-        if (tile < nFull) {
-            const uint32_t rem = q - tile * tileSpan;
+        slot = q;
+        if (tileW < nFull) {
+            const uint32_t rem = q - tileW * tileSpan;
+            const uint32_t tile = p.tile_order ? p.tile_order[tileW] : tileW;
             k = rem >> 6;
             pl = (tile << 6) + (rem & 63u);
+            slot = tile * tileSpan + rem;
         } else {
             const uint32_t rem = q - nFull * tileSpan;
             const uint32_t wl = p.npix_local - (nFull << 6);
@@ -73,7 +78,7 @@ RT_DEV void path_coordinates(const TraceParams& p, uint32_t q, uint32_t& i, uint
         const uint32_t lr = pl / p.W;
         i = pl - lr * p.W;
         j = rowset_global_row(p.rs, lr);
-        slot = q + p.sample_base;  // the call's region of the sample ring (0 without frame pipelining)
+        slot += p.sample_base;  // the call's region of the sample ring (0 without frame pipelining)
     }
 }
 
@@ -181,23 +186,25 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
 }
 
 // Next block of fresh paths for this wave (rt_params.h, "the queue of fresh paths"); false when every shard is empty.
-RT_DEV bool claim_block(const TraceParams& p, uint32_t lane, uint32_t qb, uint32_t& blkNext, uint32_t& blkEnd) {
+RT_DEV bool claim_block(const TraceParams& p, uint32_t lane, uint32_t qb, uint32_t& blkNext, uint32_t& blkEnd, uint32_t& shard) {
     for (uint32_t a = 0; a < kQueueShards; ++a) {
         const uint32_t k = (blockIdx.x + a) & (kQueueShards - 1u);
         uint32_t* head = p.shard_heads + 32u * k;
-        const uint32_t endK = p.shard_end[k];
-        uint32_t b = 0;
-        if (lane == 0) b = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-        if (b >= endK) continue;
-        if (lane == 0) b = atomicAdd(head, qb);
-        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-        if (b < endK) {
-            blkNext = b;
-            blkEnd = (b + qb) < endK ? (b + qb) : endK;
+        uint32_t c = 0;
+        if (lane == 0) c = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        if (c * kQueueShards + k >= p.dyn_blocks) continue;
+        if (lane == 0) c = atomicAdd(head, 1u);
+        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        const uint32_t b = c * kQueueShards + k;  // shard k owns the blocks k, k + 8, k + 16, ...
+        if (b < p.dyn_blocks) {
+            blkNext = p.dyn_begin + b * qb;
+            blkEnd = (blkNext + qb) < p.total_paths ? (blkNext + qb) : p.total_paths;
+            shard = k;  // where the claim succeeded (the caller claims ahead from the same shard)
             return true;
         }
     }
+    shard = kQueueShards;
     return false;
 }
 
@@ -280,6 +287,8 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     // wave-uniform queue window and prepared-path cache (48-byte slots: origin, direction, stream state, path index)
     uint32_t blkNext = 0, blkEnd = 0, cachePos = 0, cacheCnt = 0;
     bool queueEmpty = false;
+    uint32_t pendShard = kQueueShards;  // shard of the block claimed ahead (kQueueShards: none), wave-uniform
+    uint32_t pendCount = 0;             // lane 0: what that claim returned
     if (kCarry) {
         // the wave's own carried paths (rt_params.h): no cursor, no atomics
         const uint32_t nIn = p.cont_in_n[gwave];
@@ -333,10 +342,30 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                 if (cachePos == cacheCnt) {
                     if (queueEmpty) break;
                     if (blkNext == blkEnd) {
-                        if (!claim_block(p, lane, kBlk, blkNext, blkEnd)) {
-                            queueEmpty = true;
-                            break;
+                        // The next block was claimed AHEAD, when this one was taken: the atomic's round trip (two of them with the
+                        // look, ~4 us under load, 117 times per wave on C2) ran under the work on a whole block instead of
+                        // stalling the wave.  A claim that came back beyond the shard's end falls through to a fresh look.
+                        bool got = false;
+                        if (pendShard < kQueueShards) {
+                            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)pendCount);
+                            const uint32_t b = c * kQueueShards + pendShard;
+                            if (b < p.dyn_blocks) {
+                                blkNext = p.dyn_begin + b * kBlk;
+                                blkEnd = (blkNext + kBlk) < p.total_paths ? (blkNext + kBlk) : p.total_paths;
+                                got = true;
+                            } else {
+                                pendShard = kQueueShards;  // that shard is dry
+                            }
                         }
+                        if (!got) {
+                            if (!claim_block(p, lane, kBlk, blkNext, blkEnd, pendShard)) {
+                                queueEmpty = true;
+                                break;
+                            }
+                        }
+                        // (not in the frame-pipelining kernel: a wave must start everything it owns before it may carry out)
+                        if (kCarry) pendShard = kQueueShards;
+                        if (pendShard < kQueueShards && lane == 0) pendCount = atomicAdd(p.shard_heads + 32u * pendShard, 1u);  // claim ahead
                     }
                     const uint32_t nGen = (blkEnd - blkNext) < (uint32_t)kWaveSize ? (blkEnd - blkNext) : (uint32_t)kWaveSize;
                     wave_lds_handoff();  // every slot of the previous batch has been popped
@@ -380,7 +409,8 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         } else {
             while (idleMask != 0ull && !queueEmpty) {
                 if (blkNext == blkEnd) {
-                    if (!claim_block(p, lane, kBlk, blkNext, blkEnd)) {
+                    uint32_t shardUnused = 0;
+                    if (!claim_block(p, lane, kBlk, blkNext, blkEnd, shardUnused)) {
                         queueEmpty = true;
                         break;
                     }
@@ -586,6 +616,10 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         atomicAdd(&g_tl[5], (unsigned long long)itersHere);
         atomicMin(&g_tl[6], tl1);
         atomicMin(&g_tl[7], tl2);
+        {
+            const unsigned long long b = (tl2 - tl0) / 2500ull;
+            atomicAdd(&g_tlHist[b < 1023ull ? (unsigned)b : 1023u], 1u);
+        }
         atomicMax(&g_tl[12], (unsigned long long)itersHere);
         if (itersHere > 14u) atomicAdd(&g_tl[13], 1ull);
     }
@@ -633,15 +667,69 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
 // The first threads also set the queue cursors (and, frame pipelining, the control block) for the trace kernel that follows.
 __global__ void __launch_bounds__(256) rt_raygen_tables_kernel(float2* jitter, uint32_t s0, uint32_t nJitter, float2* lens, uint32_t k0,
                                                                uint32_t nLens, uint32_t sampler, uint32_t* shardHeads = nullptr,
-                                                               ShardStarts shards = ShardStarts{}, FrameCtl* ctl = nullptr) {
+                                                               FrameCtl* ctl = nullptr) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (shardHeads && k < kQueueShards) shardHeads[32u * k] = shards.begin[k];
+    if (shardHeads && k < kQueueShards) shardHeads[32u * k] = 0u;
     if (ctl && k == 0) ctl->oldest_open = 0xffffffffu;
     if (k < nJitter) jitter[k] = make_float2(halton(s0 + k, 2), halton(s0 + k, 3));
     if (k < nLens) {
         float lx, ly;
         halton_disk_4_5(k0 + k, lx, ly, sampler);
         lens[k] = make_float2(lx, ly);
+    }
+}
+
+// ====================================================== work order of the tiles (scheduling only)
+// A persistent launch ends with the tail of whatever it started last; if those are 51-segment paths through the glass
+// spheres, most of the chip waits for them (3 % of a C2 launch, 16 % at spp 16).  One pilot ray per full tile (its middle
+// pixel, sample 1) is traced through the production scan when an accumulation starts; rt_tile_order_kernel then sorts the
+// tiles by the material of the pilot's first hit -- glass, metal, anything else, nothing -- and the launches of the
+// accumulation take them in that order: the sky, whose paths end after one scan, comes last.  Results do not depend on
+// the order (every path has its own slot and stream); only the schedule does.
+__global__ void __launch_bounds__(256) rt_pilot_rays_kernel(const TraceParams p, uint32_t nFull, float* rays) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nFull) return;
+    const uint32_t pl = (t << 6) + 32u;
+    const uint32_t lr = pl / p.W;
+    V3 o, d;
+    gen_primary_ray(p, pl - lr * p.W, rowset_global_row(p.rs, lr), 1u, o, d);
+    float* w = rays + 6 * (size_t)t;
+    w[0] = o.x; w[1] = o.y; w[2] = o.z; w[3] = d.x; w[4] = d.y; w[5] = d.z;
+}
+// hits: rt_unit_closest_hit records (10 floats; [1] = original sphere index as bits, < 0 = miss); one workgroup
+__global__ void __launch_bounds__(1024) rt_tile_order_kernel(const float* hits, uint32_t nFull, const uint32_t* matTypeByOrig,
+                                                            uint32_t* order) {
+    __shared__ uint32_t waveTot[16];
+    __shared__ uint32_t base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    if (tid == 0) base = 0u;
+    __syncthreads();
+    for (int c = 3; c >= 0; --c) {  // glass, metal, other hits, misses
+        for (uint32_t start = 0; start < nFull; start += 1024u) {
+            const uint32_t t = start + tid;
+            bool flag = false;
+            if (t < nFull) {
+                const int oidx = __float_as_int(hits[10 * (size_t)t + 1]);
+                int cls = 0;
+                if (oidx >= 0) {
+                    const uint32_t ty = matTypeByOrig[oidx];
+                    cls = ty == RT_MAT_DIELECTRIC_TRANSPARENT ? 3 : (ty == RT_MAT_METAL ? 2 : 1);
+                }
+                flag = cls == c;
+            }
+            const uint64_t m = __ballot(flag);
+            if (lane == 0) waveTot[w] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t off = 0, tot = 0;
+            for (uint32_t k = 0; k < 16u; ++k) {
+                off += k < w ? waveTot[k] : 0u;
+                tot += waveTot[k];
+            }
+            if (flag) order[base + off + prefix_count(m)] = t;
+            __syncthreads();
+            if (tid == 0) base += tot;
+            __syncthreads();
+        }
     }
 }
 

@@ -31,12 +31,13 @@ RT_DEV unsigned long long rt_stamp() {
 #endif
 
 #ifdef RT_TIMELINE
-static __device__ unsigned long long g_tl[16];  // diagnostic build only: wall-clock landmarks of the last trace kernel
+static __device__ unsigned long long g_tl[16];
+static __device__ unsigned int g_tlHist[1024];  // waves leaving the loop per 25-us bucket of their own lifetime  // diagnostic build only: wall-clock landmarks of the last trace kernel
 #endif
 
 constexpr int kWaveSize = 64;
 constexpr uint32_t kMaxLevels = 6;  // levels of group bounds (4-ary): 128 * 4^5 groups at most
-constexpr uint32_t kQueueBlock = 256;  // paths a wave takes from the global queue per atomic
+constexpr uint32_t kQueueBlock = 128;  // paths a wave takes from the global queue per claim (claimed one block ahead: rt_kernels.h)
 constexpr uint32_t kCarryQueueBlock = 128; // ... in the frame-pipelining kernel (rt_kernels.h): two batches of the path cache
 
 // ---- frame pipelining (progressive use: SpheresApp::OnRender adds ONE sample per frame, spheres-app.cpp:163-184).
@@ -46,13 +47,12 @@ constexpr uint32_t kCarryQueueBlock = 128; // ... in the frame-pipelining kernel
 // call order, and only once no carried path belongs to them (FrameCtl::oldest_open).
 // The queue of fresh paths (every trace kernel): a wave owns TraceParams::static_blocks blocks statically (block index =
 // wave index: no claim, and no rush of 4,096 simultaneous atomics when the kernel starts); the rest of the launch's paths
-// sits in eight shards (a workgroup prefers shard blockIdx & 7 -- workgroups are dealt round-robin over the 8 XCDs -- and
-// steals from the others when its own is dry) whose cursors are 128 bytes apart, and a wave LOOKS at a cursor before it
-// claims: same-line atomics are served one behind the other (~11 ns each), loads are not.
+// sits in eight INTERLEAVED shards -- shard k owns the blocks k, k + 8, k + 16, ... of the work order, so all shards move
+// through the launch's work order together and the tiles sorted to its end (the sky) really are what the launch ends with;
+// a workgroup prefers shard blockIdx & 7 (workgroups are dealt round-robin over the 8 XCDs) and steals from the others when
+// its own is dry.  The cursors are 128 bytes apart, and a wave LOOKS at a cursor before it claims: same-line atomics are
+// served one behind the other (~11 ns each), loads are not.
 constexpr uint32_t kQueueShards = 8;
-struct ShardStarts {
-    uint32_t begin[kQueueShards];
-};
 
 struct ContEntry {
     float4 a, b, c, d, e;  // ro.xyz rd.x | rd.yz thr.xy | thr.z rad.xyz | xoshiro s0..s3 | slot, depth, region sequence & 255, traversals
@@ -114,6 +114,7 @@ struct TraceParams {
     uint32_t sampler;     // RT_SAMPLER_* flags (rt_api.h): 0 = the reference's mappings
     uint64_t seed;
     const uint32_t* path_list;  // optional explicit (i, j, s) triples (unit tests)
+    const uint32_t* tile_order; // optional: full tile of WORK position w is image tile tile_order[w] (expensive tiles first)
     const float2* jitter_tab;   // [spp_pass] Halton2D(s;2,3) for s = s0.. (rt_raygen_tables_kernel), or null
     const float2* lens_tab;     // [.] HaltonSampleDisk(k;4,5) for k = lens_k0.., or null
     uint32_t lens_k0;
@@ -131,10 +132,10 @@ struct TraceParams {
     uint32_t min_iters;         // iterations a wave runs before it may carry its paths out
     uint32_t queue_block;       // paths per queue block in the carrying kernel (a multiple of 64)
     uint32_t static_blocks;     // blocks every wave owns without asking (block index = wave index)
-    uint32_t shard_begin[kQueueShards], shard_end[kQueueShards];  // path ranges of the queue shards (multiples of 64)
+    uint32_t dyn_begin, dyn_blocks;  // the shards' part of the work order: first path and number of blocks
     uint32_t sample_base;       // first 12-byte slot of this call's region in the sample ring (0 without pipelining)
     uint32_t ray_cache_off16;  // float4 offset of the per-wave prepared-path caches in dynamic LDS, 0 = no cache
-    uint32_t* shard_heads;      // [kQueueShards][32]: [k][0] = cursor of queue shard k (set to shard_begin[k] before launch)
+    uint32_t* shard_heads;      // [kQueueShards][32]: [k][0] = cursor of queue shard k (blocks claimed from it; zeroed before launch)
     unsigned long long* counters;  // [0] traversals, [1] segments
 };
 

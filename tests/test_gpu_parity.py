@@ -803,9 +803,12 @@ def _render_with_env(monkeypatch, env, sc, W, H, s1, depth=50, seed=1):
     {"RT_BLOCKS_PER_CU": "2"},                                 # more workgroups than fit: the surplus starts as others end
     {"RT_SCAN": "valu", "RT_BLOCKS_PER_CU": "2", "RT_SHADOW_GRID": "0"},
     {"RT_SHADOW_GRID": "0", "RT_MATS_LDS": "0", "RT_RAY_CACHE": "0", "RT_BLOCK_THREADS": "512"},
+    {"RT_TILE_ORDER": "0"},                                    # tiles in image order instead of expensive-first
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_launch_and_layout_knobs_give_the_same_bits(hip, scenes_mod, monkeypatch, env):
     W, H, s1 = 161, 103, 5  # ragged: the last tile of the sample buffer is 9 pixels wide
+    if "RT_TILE_ORDER" in env:
+        W, H = 483, 309       # enough tiles (2,331) for the expensive-first work order to be built at all; still ragged
     sc = scenes_mod.build_scene("cover", 1, W, H)
     hip.upload(sc)
     sa = hip.render(W, H, 1, s1, 50, 1)
