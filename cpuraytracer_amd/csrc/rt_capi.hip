@@ -114,6 +114,7 @@ struct rt_ctx {
     bool tileOrderValid = false;
     DevBuf<float> pilotRays, pilotHits;
     DevBuf<uint32_t> tileOrder, matType;
+    DevBuf<uint8_t> tileClass;
 
     // frame pipelining (rt_set_frame_pipelining; rt_params.h): regions of a sample ring, two continuation buffers
     uint32_t pipeDepth = 0;     // calls a path may be carried across (0 = off)
@@ -684,15 +685,17 @@ static int LaunchClosest(rt_ctx* ctx, const float* dRays, uint32_t n, float* dOu
     return RT_OK;
 }
 
-// Work order of the full tiles for the accumulation that is starting (rt_kernels.h, rt_tile_order_kernel): one pilot ray per
-// tile through the production scan, then a stable sort by the first hit's material.  All on the stream, no host wait.
+// Work order of the full tiles for the accumulation that is starting (rt_kernels.h, rt_tile_order_kernel): three pilot rays per
+// tile through the production scan, then a stable sort by the most expensive first-hit material.  All on the stream, no host wait.
 static int BuildTileOrder(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t npix) {
     ctx->tileOrderValid = false;
     const uint32_t nFull = npix >> 6;
     if (!ctx->useTileOrder || nFull < 2u * (uint32_t)ctx->cuCount) return RT_OK;  // too little work for the order to matter
     int rc;
-    if ((rc = ctx->pilotRays.Reserve((size_t)nFull * 6)) != RT_OK) return rc;
-    if ((rc = ctx->pilotHits.Reserve((size_t)nFull * 10)) != RT_OK) return rc;
+    const uint32_t nPilot = nFull * rtd::kPilotsPerTile;
+    if ((rc = ctx->pilotRays.Reserve((size_t)nPilot * 6)) != RT_OK) return rc;
+    if ((rc = ctx->pilotHits.Reserve((size_t)nPilot * 10)) != RT_OK) return rc;
+    if ((rc = ctx->tileClass.Reserve(nFull)) != RT_OK) return rc;
     if ((rc = ctx->tileOrder.Reserve(nFull)) != RT_OK) return rc;
     rtd::TraceParams tp = ctx->base;
     tp.W = W;
@@ -702,11 +705,12 @@ static int BuildTileOrder(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uin
     tp.sampler = ctx->sampler;
     tp.jitter_tab = nullptr;
     tp.lens_tab = nullptr;
-    hipLaunchKernelGGL(rtd::rt_pilot_rays_kernel, dim3((nFull + 255) / 256), dim3(256), 0, ctx->stream, tp, nFull, ctx->pilotRays.ptr);
+    hipLaunchKernelGGL(rtd::rt_pilot_rays_kernel, dim3((nPilot + 255) / 256), dim3(256), 0, ctx->stream, tp, nFull, ctx->pilotRays.ptr);
     RT_HIP(hipGetLastError());
-    if ((rc = LaunchClosest(ctx, ctx->pilotRays.ptr, nFull, ctx->pilotHits.ptr)) != RT_OK) return rc;
-    hipLaunchKernelGGL(rtd::rt_tile_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->pilotHits.ptr, nFull, ctx->matType.ptr,
-                       ctx->tileOrder.ptr);
+    if ((rc = LaunchClosest(ctx, ctx->pilotRays.ptr, nPilot, ctx->pilotHits.ptr)) != RT_OK) return rc;
+    hipLaunchKernelGGL(rtd::rt_tile_class_kernel, dim3((nFull + 255) / 256), dim3(256), 0, ctx->stream, ctx->pilotHits.ptr, nFull, W,
+                       ctx->matType.ptr, ctx->tileClass.ptr);
+    hipLaunchKernelGGL(rtd::rt_tile_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->tileClass.ptr, nFull, ctx->tileOrder.ptr);
     RT_HIP(hipGetLastError());
     ctx->tileOrderValid = true;
     return RT_OK;
@@ -899,7 +903,7 @@ int rt_create(int device_ordinal, rt_ctx** out) {
     ctx->forceGlobal = EnvU32("RT_FORCE_GLOBAL_TABLES", 0) != 0;
     ctx->blockThreads = EnvU32("RT_BLOCK_THREADS", ctx->useMfma ? 1024 : 256);
     if (ctx->blockThreads != 256 && ctx->blockThreads != 512 && ctx->blockThreads != 1024) ctx->blockThreads = 256;
-    int rc = ctx->queue.Reserve(rtd::kQueueShards * 32);  // eight queue cursors, 128 bytes apart
+    int rc = ctx->queue.Reserve(rtd::kQueueShards * rtd::kShardStrideWords);  // eight queue cursors, 128 bytes apart
     if (rc == RT_OK) rc = ctx->counters.Reserve(2);
     if (rc != RT_OK) return rc;
     {
@@ -941,6 +945,7 @@ void rt_destroy(rt_ctx* ctx) {
     ctx->pilotRays.Release();
     ctx->pilotHits.Release();
     ctx->tileOrder.Release();
+    ctx->tileClass.Release();
     ctx->matType.Release();
     ctx->ring.Release();
     ctx->cont[0].Release();
@@ -1530,8 +1535,29 @@ int rt_debug_timeline(rt_ctx* ctx, unsigned long long out[16]) {
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipStreamSynchronize(ctx->stream));
     RT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(rtd::g_tl), 16 * sizeof(unsigned long long)));
-    unsigned long long z[16] = {~0ull, 0, 0, 0, 0, 0, ~0ull, ~0ull, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long z[16] = {~0ull, 0, 0, 0, 0, 0, ~0ull, ~0ull, 0, 0, 0, 0, 0, 0, ~0ull, 0};
     RT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_tl), z, sizeof(z)));
+    return RT_OK;
+}
+int rt_debug_timeline_waves(rt_ctx* ctx, unsigned long long out[4096 * 8]) {
+    if (!ctx || !out) return Fail(RT_ERR_INVALID_ARG, "rt_debug_timeline_waves: invalid argument");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(rtd::g_tlWave), 4096 * 8 * sizeof(unsigned long long)));
+    return RT_OK;
+}
+int rt_debug_timeline_ring(rt_ctx* ctx, unsigned long long out[4096 * 16]) {
+    if (!ctx || !out) return Fail(RT_ERR_INVALID_ARG, "rt_debug_timeline_ring: invalid argument");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(rtd::g_tlRing), 4096 * 16 * sizeof(unsigned long long)));
+    return RT_OK;
+}
+int rt_debug_timeline_last(rt_ctx* ctx, unsigned int out[4096 * 4]) {
+    if (!ctx || !out) return Fail(RT_ERR_INVALID_ARG, "rt_debug_timeline_last: invalid argument");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(rtd::g_tlLast), 4096 * 4 * sizeof(unsigned int)));
     return RT_OK;
 }
 int rt_debug_timeline_hist(rt_ctx* ctx, unsigned int out[1024]) {

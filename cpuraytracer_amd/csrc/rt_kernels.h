@@ -186,14 +186,29 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
 }
 
 // Next block of fresh paths for this wave (rt_params.h, "the queue of fresh paths"); false when every shard is empty.
-RT_DEV bool claim_block(const TraceParams& p, uint32_t lane, uint32_t qb, uint32_t& blkNext, uint32_t& blkEnd, uint32_t& shard) {
+// What one wave learns about an empty shard it tells its workgroup (SceneConsts::dry_mask, LDS): when a launch runs out of
+// work, 4,096 waves asking 8 cursors each are 32,000 requests that the memory side serves one behind the other -- they
+// alone were the last 0.4 ms of a launch (tools/timeline_waves.py: a claim took 160-400 us there).
+RT_DEV uint32_t dry_shards(SceneConsts* ldsK) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ldsK->dry_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+RT_DEV void mark_dry(SceneConsts* ldsK, uint32_t lane, uint32_t k) {
+    if (lane == 0) __hip_atomic_fetch_or(&ldsK->dry_mask, 1u << k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+RT_DEV bool claim_block(const TraceParams& p, SceneConsts* ldsK, uint32_t lane, uint32_t qb, uint32_t& blkNext, uint32_t& blkEnd,
+                        uint32_t& shard) {
+    uint32_t dry = dry_shards(ldsK);
     for (uint32_t a = 0; a < kQueueShards; ++a) {
         const uint32_t k = (blockIdx.x + a) & (kQueueShards - 1u);
-        uint32_t* head = p.shard_heads + 32u * k;
+        if ((dry >> k) & 1u) continue;
+        uint32_t* head = p.shard_heads + kShardStrideWords * k;
         uint32_t c = 0;
         if (lane == 0) c = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-        if (c * kQueueShards + k >= p.dyn_blocks) continue;
+        if (c * kQueueShards + k >= p.dyn_blocks) {
+            mark_dry(ldsK, lane, k);
+            continue;
+        }
         if (lane == 0) c = atomicAdd(head, 1u);
         c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
         const uint32_t b = c * kQueueShards + k;  // shard k owns the blocks k, k + 8, k + 16, ...
@@ -203,6 +218,8 @@ RT_DEV bool claim_block(const TraceParams& p, uint32_t lane, uint32_t qb, uint32
             shard = k;  // where the claim succeeded (the caller claims ahead from the same shard)
             return true;
         }
+        mark_dry(ldsK, lane, k);
+        dry = dry_shards(ldsK);  // what the others found in the meantime
     }
     shard = kQueueShards;
     return false;
@@ -324,6 +341,13 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     float4* rayCache = kCache ? smem + p.ray_cache_off16 + (threadIdx.x / kWaveSize) * (kRayCacheBytes / 16) : nullptr;
 
     unsigned long long dbgScan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef RT_TIMELINE
+    unsigned long long tlDrain = 0ull;  // when this wave had nothing left to start
+    uint32_t drainIters = 0;            // iterations after that
+    unsigned long long tlLastClaim = 0ull;
+    uint32_t tlBorn = 0;  // per lane: when its path was started
+    uint32_t tlBlocks = 0, tlLastBlock = 0, tlIters = 0;
+#endif
     (void)dbgScan;
 #ifdef RT_STAMPS
     unsigned long long cyRefill = 0, cyScan = 0, cyTrans = 0, cyIters = 0, cyHit[6] = {0, 0, 0, 0, 0, 0};
@@ -354,19 +378,32 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                                 blkEnd = (blkNext + kBlk) < p.total_paths ? (blkNext + kBlk) : p.total_paths;
                                 got = true;
                             } else {
+                                mark_dry(ldsK, lane, pendShard);
                                 pendShard = kQueueShards;  // that shard is dry
                             }
                         }
                         if (!got) {
-                            if (!claim_block(p, lane, kBlk, blkNext, blkEnd, pendShard)) {
+                            if (!claim_block(p, ldsK, lane, kBlk, blkNext, blkEnd, pendShard)) {
                                 queueEmpty = true;
                                 break;
                             }
                         }
                         // (not in the frame-pipelining kernel: a wave must start everything it owns before it may carry out)
                         if (kCarry) pendShard = kQueueShards;
-                        if (pendShard < kQueueShards && lane == 0) pendCount = atomicAdd(p.shard_heads + 32u * pendShard, 1u);  // claim ahead
+                        if (pendShard < kQueueShards && ((dry_shards(ldsK) >> pendShard) & 1u)) pendShard = kQueueShards;
+                        if (pendShard < kQueueShards && lane == 0) pendCount = atomicAdd(p.shard_heads + kShardStrideWords * pendShard, 1u);  // claim ahead
                     }
+#ifdef RT_TIMELINE
+                    if (blkNext % kBlk == 0u) {
+                        tlLastClaim = __builtin_amdgcn_s_memrealtime();
+                        ++tlBlocks;
+                        tlLastBlock = blkNext / kBlk;
+#ifdef RT_TIMELINE_RING
+                        if (!kCarry && gwave < 4096u && lane == 0)
+                            g_tlRing[16u * gwave + (tlBlocks & 15u)] = ((tlLastClaim - tl0) << 24) | (unsigned long long)(__popcll(__ballot(state != kIdle)) & 127) << 17 | (tlLastBlock >> 3);
+#endif
+                    }
+#endif
                     const uint32_t nGen = (blkEnd - blkNext) < (uint32_t)kWaveSize ? (blkEnd - blkNext) : (uint32_t)kWaveSize;
                     wave_lds_handoff();  // every slot of the previous batch has been popped
                     if (lane < nGen) {
@@ -402,6 +439,9 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                     pathTrav = 0;
                     if (kCarry) seq8 = p.region_seq & 255u;
                     state = kNeedClosest;
+#ifdef RT_TIMELINE
+                    tlBorn = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tl0);
+#endif
                 }
                 cachePos += want < avail ? want : avail;
                 idleMask = __ballot(state == kIdle);
@@ -410,7 +450,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
             while (idleMask != 0ull && !queueEmpty) {
                 if (blkNext == blkEnd) {
                     uint32_t shardUnused = 0;
-                    if (!claim_block(p, lane, kBlk, blkNext, blkEnd, shardUnused)) {
+                    if (!claim_block(p, ldsK, lane, kBlk, blkNext, blkEnd, shardUnused)) {
                         queueEmpty = true;
                         break;
                     }
@@ -434,6 +474,13 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
             }
         }
         if (__ballot(state != kIdle) == 0ull) break;  // queue empty and every lane drained
+#ifdef RT_TIMELINE
+        ++tlIters;
+        if (queueEmpty && cachePos == cacheCnt) {
+            if (tlDrain == 0ull) tlDrain = __builtin_amdgcn_s_memrealtime();
+            ++drainIters;
+        }
+#endif
         if (kCarry) {
             ++itersHere;
             // Nothing left to start: carry the live paths into the next call's kernel instead of running their tail here.
@@ -577,6 +624,12 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
             *reinterpret_cast<float3*>(p.samples + (size_t)q * 3) = make_float3(rad.x * expo, rad.y * expo, rad.z * expo);
             if (p.trav_out) p.trav_out[q] = pathTrav;
             state = kIdle;
+#ifdef RT_TIMELINE
+            if (!kCarry && tlDrain != 0ull && gwave < 4096u) {
+                unsigned int* w = g_tlLast + 4u * gwave;
+                w[0] = tlBorn; w[1] = depth; w[2] = q; w[3] = pathTrav;
+            }
+#endif
         }
         RT_STAMP(ts3);
 #ifdef RT_STAMPS
@@ -606,22 +659,32 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         }
     }
 #ifdef RT_TIMELINE
-    if (lane == 0) {  // g_tl: [0] min start, [1] max staged, [2] max loop exit, [3] sum of (exit - start), [4] waves, [5] sum iterations
+    if (lane == 0) {
         const unsigned long long tl2 = __builtin_amdgcn_s_memrealtime();
-        atomicMin(&g_tl[0], tl0);
-        atomicMax(&g_tl[1], tl1);
-        atomicMax(&g_tl[2], tl2);
-        atomicAdd(&g_tl[3], tl2 - tl0);
-        atomicAdd(&g_tl[4], 1ull);
-        atomicAdd(&g_tl[5], (unsigned long long)itersHere);
-        atomicMin(&g_tl[6], tl1);
-        atomicMin(&g_tl[7], tl2);
-        {
-            const unsigned long long b = (tl2 - tl0) / 2500ull;
-            atomicAdd(&g_tlHist[b < 1023ull ? (unsigned)b : 1023u], 1u);
+        if (!kCarry) {
+            // one 64-byte record per wave, plain stores: shared counters here would be 4,096 x n same-line atomics at ~11 ns
+            // each when the waves leave together -- the instrument would make the tail it is meant to measure
+            if (gwave < 4096u) {
+                unsigned long long* w = g_tlWave + 8u * gwave;
+                w[0] = tl0; w[1] = tlDrain != 0ull ? tlDrain : tl2; w[2] = tl2; w[3] = tlBlocks; w[4] = tlLastBlock; w[5] = tlLastClaim;
+                w[6] = tlIters; w[7] = drainIters;
+            }
+        } else {  // g_tl: [0] min start, [1] max staged, [2] max loop exit, [3] sum of (exit - start), [4] waves, [5] sum iterations
+            atomicMin(&g_tl[0], tl0);
+            atomicMax(&g_tl[1], tl1);
+            atomicMax(&g_tl[2], tl2);
+            atomicAdd(&g_tl[3], tl2 - tl0);
+            atomicAdd(&g_tl[4], 1ull);
+            atomicAdd(&g_tl[5], (unsigned long long)itersHere);
+            atomicMin(&g_tl[6], tl1);
+            atomicMin(&g_tl[7], tl2);
+            {
+                const unsigned long long b = (tl2 - tl0) / 2500ull;
+                atomicAdd(&g_tlHist[b < 1023ull ? (unsigned)b : 1023u], 1u);
+            }
+            atomicMax(&g_tl[12], (unsigned long long)itersHere);
+            if (itersHere > 14u) atomicAdd(&g_tl[13], 1ull);
         }
-        atomicMax(&g_tl[12], (unsigned long long)itersHere);
-        if (itersHere > 14u) atomicAdd(&g_tl[13], 1ull);
     }
 #endif
     // counters: wave reduce, one atomic pair per wave
@@ -669,7 +732,7 @@ __global__ void __launch_bounds__(256) rt_raygen_tables_kernel(float2* jitter, u
                                                                uint32_t nLens, uint32_t sampler, uint32_t* shardHeads = nullptr,
                                                                FrameCtl* ctl = nullptr) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (shardHeads && k < kQueueShards) shardHeads[32u * k] = 0u;
+    if (shardHeads && k < kQueueShards) shardHeads[kShardStrideWords * k] = 0u;
     if (ctl && k == 0) ctl->oldest_open = 0xffffffffu;
     if (k < nJitter) jitter[k] = make_float2(halton(s0 + k, 2), halton(s0 + k, 3));
     if (k < nLens) {
@@ -681,55 +744,94 @@ __global__ void __launch_bounds__(256) rt_raygen_tables_kernel(float2* jitter, u
 
 // ====================================================== work order of the tiles (scheduling only)
 // A persistent launch ends with the tail of whatever it started last; if those are 51-segment paths through the glass
-// spheres, most of the chip waits for them (3 % of a C2 launch, 16 % at spp 16).  One pilot ray per full tile (its middle
-// pixel, sample 1) is traced through the production scan when an accumulation starts; rt_tile_order_kernel then sorts the
-// tiles by the material of the pilot's first hit -- glass, metal, anything else, nothing -- and the launches of the
-// accumulation take them in that order: the sky, whose paths end after one scan, comes last.  Results do not depend on
-// the order (every path has its own slot and stream); only the schedule does.
+// spheres, most of the chip waits for them (2 % of a C2 launch, 11 % at spp 16).  Three pilot rays per full tile (its first,
+// middle and last pixel, sample 1) are traced through the production scan when an accumulation starts; the tile's class is
+// the most expensive material among their first hits -- nothing, anything else, metal, glass -- and the launches of the
+// accumulation take the tiles by descending class: the sky, whose paths end after one scan, comes last.  Results do not
+// depend on the order (every path has its own slot and stream); only the schedule does.
+constexpr uint32_t kPilotsPerTile = 3;
 __global__ void __launch_bounds__(256) rt_pilot_rays_kernel(const TraceParams p, uint32_t nFull, float* rays) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nFull) return;
-    const uint32_t pl = (t << 6) + 32u;
+    if (t >= nFull * kPilotsPerTile) return;
+    const uint32_t tile = t / kPilotsPerTile, which = t - tile * kPilotsPerTile;
+    const uint32_t pl = (tile << 6) + (which == 0u ? 0u : (which == 1u ? 32u : 63u));
     const uint32_t lr = pl / p.W;
     V3 o, d;
     gen_primary_ray(p, pl - lr * p.W, rowset_global_row(p.rs, lr), 1u, o, d);
     float* w = rays + 6 * (size_t)t;
     w[0] = o.x; w[1] = o.y; w[2] = o.z; w[3] = d.x; w[4] = d.y; w[5] = d.z;
 }
-// hits: rt_unit_closest_hit records (10 floats; [1] = original sphere index as bits, < 0 = miss); one workgroup
-__global__ void __launch_bounds__(1024) rt_tile_order_kernel(const float* hits, uint32_t nFull, const uint32_t* matTypeByOrig,
-                                                            uint32_t* order) {
-    __shared__ uint32_t waveTot[16];
-    __shared__ uint32_t base;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    if (tid == 0) base = 0u;
-    __syncthreads();
-    for (int c = 3; c >= 0; --c) {  // glass, metal, other hits, misses
-        for (uint32_t start = 0; start < nFull; start += 1024u) {
-            const uint32_t t = start + tid;
-            bool flag = false;
-            if (t < nFull) {
-                const int oidx = __float_as_int(hits[10 * (size_t)t + 1]);
-                int cls = 0;
-                if (oidx >= 0) {
-                    const uint32_t ty = matTypeByOrig[oidx];
-                    cls = ty == RT_MAT_DIELECTRIC_TRANSPARENT ? 3 : (ty == RT_MAT_METAL ? 2 : 1);
-                }
-                flag = cls == c;
-            }
-            const uint64_t m = __ballot(flag);
-            if (lane == 0) waveTot[w] = (uint32_t)__popcll(m);
-            __syncthreads();
-            uint32_t off = 0, tot = 0;
-            for (uint32_t k = 0; k < 16u; ++k) {
-                off += k < w ? waveTot[k] : 0u;
-                tot += waveTot[k];
-            }
-            if (flag) order[base + off + prefix_count(m)] = t;
-            __syncthreads();
-            if (tid == 0) base += tot;
-            __syncthreads();
+// hits: rt_unit_closest_hit records (10 floats; [1] = original sphere index as bits, < 0 = miss), kPilotsPerTile per tile
+RT_DEV uint32_t pilot_class(const float* hits, uint32_t t, const uint32_t* matTypeByOrig) {
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < kPilotsPerTile; ++k) {
+        const int oidx = __float_as_int(hits[10 * ((size_t)t * kPilotsPerTile + k) + 1]);
+        if (oidx >= 0) {
+            const uint32_t ty = matTypeByOrig[oidx];
+            const uint32_t ck = ty == RT_MAT_DIELECTRIC_TRANSPARENT ? 3u : (ty == RT_MAT_METAL ? 2u : 1u);
+            c = ck > c ? ck : c;
         }
+    }
+    return c;
+}
+// A tile next to a glass tile -- left, right, in the row above or below -- counts as glass too: the cap of a glass sphere
+// that sticks out into the sky can be narrower than the pilots' spacing, and its 51-segment paths, started with the sky in
+// the launch's last half millisecond, were the last three waves of a C2 launch (+1 % of its duration; tools/timeline_bulk.py).
+__global__ void __launch_bounds__(256) rt_tile_class_kernel(const float* hits, uint32_t nFull, uint32_t W, const uint32_t* matTypeByOrig,
+                                                            uint8_t* cls) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nFull) return;
+    uint32_t c = pilot_class(hits, t, matTypeByOrig);
+    if (c != 3u) {
+        const int64_t first = (int64_t)t << 6;
+        const int64_t near[6] = {first - 64, first + 64, first - (int64_t)W, first - (int64_t)W + 63, first + (int64_t)W, first + (int64_t)W + 63};
+        for (int k = 0; k < 6; ++k) {
+            const int64_t n = near[k] >> 6;  // the tile of that pixel
+            if (near[k] >= 0 && n < (int64_t)nFull && pilot_class(hits, (uint32_t)n, matTypeByOrig) == 3u) c = 3u;
+        }
+    }
+    cls[t] = (uint8_t)c;
+}
+// Stable counting sort of the tiles by descending class; one workgroup, thread k owns a contiguous run of tiles.
+__global__ void __launch_bounds__(1024) rt_tile_order_kernel(const uint8_t* cls, uint32_t nFull, uint32_t* order) {
+    __shared__ uint32_t waveTot[16][4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint32_t per = (nFull + 1023u) / 1024u;
+    const uint32_t t0 = tid * per < nFull ? tid * per : nFull, t1 = (t0 + per) < nFull ? (t0 + per) : nFull;
+    uint32_t cnt[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t c = cls[t];
+        for (uint32_t k = 0; k < 4u; ++k) cnt[k] += c == k ? 1u : 0u;
+    }
+    uint32_t pos[4];  // where this thread's tiles of class k start
+    for (uint32_t k = 0; k < 4u; ++k) {
+        uint32_t incl = cnt[k];
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+            if ((int)lane >= off) incl += v;
+        }
+        if (lane == 63u) waveTot[w][k] = incl;
+        pos[k] = incl - cnt[k];
+    }
+    __syncthreads();
+    uint32_t base = 0;
+    for (int k = 3; k >= 0; --k) {
+        uint32_t before = 0, tot = 0;
+        for (uint32_t v = 0; v < 16u; ++v) {
+            before += v < w ? waveTot[v][k] : 0u;
+            tot += waveTot[v][k];
+        }
+        pos[k] += base + before;
+        base += tot;
+    }
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t c = cls[t];
+        uint32_t at = 0;
+        for (uint32_t k = 0; k < 4u; ++k) {
+            at = c == k ? pos[k] : at;
+            pos[k] += c == k ? 1u : 0u;
+        }
+        order[at] = t;
     }
 }
 

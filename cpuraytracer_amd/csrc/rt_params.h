@@ -32,6 +32,9 @@ RT_DEV unsigned long long rt_stamp() {
 
 #ifdef RT_TIMELINE
 static __device__ unsigned long long g_tl[16];
+static __device__ unsigned long long g_tlRing[4096 * 16];  // per wave: the last 16 (claim time << 24 | block index / 64) records
+static __device__ unsigned int g_tlLast[4096 * 4];  // per wave, the last path to finish: start time (low word), depth, slot, traversals
+static __device__ unsigned long long g_tlWave[4096 * 8];  // per wave: start, drain start, exit, blocks, last block, last claim, iterations, drain iterations
 static __device__ unsigned int g_tlHist[1024];  // waves leaving the loop per 25-us bucket of their own lifetime  // diagnostic build only: wall-clock landmarks of the last trace kernel
 #endif
 
@@ -53,6 +56,10 @@ constexpr uint32_t kCarryQueueBlock = 128; // ... in the frame-pipelining kernel
 // its own is dry.  The cursors are 128 bytes apart, and a wave LOOKS at a cursor before it claims: same-line atomics are
 // served one behind the other (~11 ns each), loads are not.
 constexpr uint32_t kQueueShards = 8;
+#ifndef RT_SHARD_STRIDE_WORDS
+#define RT_SHARD_STRIDE_WORDS 32
+#endif
+constexpr uint32_t kShardStrideWords = RT_SHARD_STRIDE_WORDS;  // distance of the cursors in 32-bit words
 
 struct ContEntry {
     float4 a, b, c, d, e;  // ro.xyz rd.x | rd.yz thr.xy | thr.z rad.xyz | xoshiro s0..s3 | slot, depth, region sequence & 255, traversals
@@ -135,7 +142,7 @@ struct TraceParams {
     uint32_t dyn_begin, dyn_blocks;  // the shards' part of the work order: first path and number of blocks
     uint32_t sample_base;       // first 12-byte slot of this call's region in the sample ring (0 without pipelining)
     uint32_t ray_cache_off16;  // float4 offset of the per-wave prepared-path caches in dynamic LDS, 0 = no cache
-    uint32_t* shard_heads;      // [kQueueShards][32]: [k][0] = cursor of queue shard k (blocks claimed from it; zeroed before launch)
+    uint32_t* shard_heads;      // [kQueueShards][kShardStrideWords]: [k][0] = cursor of queue shard k (blocks claimed from it; zeroed before launch)
     unsigned long long* counters;  // [0] traversals, [1] segments
 };
 
@@ -157,6 +164,7 @@ struct SceneConsts {
     const float2* lens_tab;
     uint32_t exit_age_max;  // frame pipelining: 1 + the largest region age among the paths this workgroup carried out (0: none)
     uint32_t exit_ticket;   // waves of this workgroup that have left the loop
+    uint32_t dry_mask;      // bit k: some wave of this workgroup has seen queue shard k empty (nobody asks memory again)
 };
 constexpr uint32_t kSceneConstBytes = 256;                         // SceneConsts at the start of the dynamic LDS image ...
 constexpr uint32_t kConstBytes = kSceneConstBytes + 8 * 256;       // ... followed by the elementary functions' tables (255 words)
@@ -173,7 +181,7 @@ RT_DEV void fill_consts(const TraceParams& p, SceneConsts& k) {
     k.sg_nx = p.sg_nx; k.sg_ny = p.sg_ny; k.sg_nglobal = p.sg_nglobal; k.sg_enabled = p.sg_enabled;
     k.W = p.W; k.H = p.H; k.s0 = p.s0; k.lens_k0 = p.lens_k0; k.sampler = p.sampler;
     k.jitter_tab = p.jitter_tab; k.lens_tab = p.lens_tab;
-    k.exit_age_max = 0u; k.exit_ticket = 0u;
+    k.exit_age_max = 0u; k.exit_ticket = 0u; k.dry_mask = 0u;
 }
 
 // --------------------------------------------------------------------------- row sets
