@@ -155,6 +155,7 @@ struct SceneLayout {
     uint32_t nLevels = 1;         // level nLevels-1 is the top level (<= topMax nodes), filtered on the matrix cores
     uint32_t nGroups = 0;         // = levelCnt[0], a multiple of 4
     float boundNorm = 0.f;        // max |C| + R
+    unsigned long long singleMask[2] = {0ull, 0ull};  // groups of one sphere, in the flat scan's bitmap coordinates
 };
 
 // Conservative bounding sphere of a set of spheres, in the filter's (C, |C|^2 - Rf^2) form.
@@ -376,6 +377,15 @@ static void BuildLayout(const rt_sphere* sp, uint32_t n, uint32_t topMax, SceneL
             L.orig[(size_t)gi * 4 + m] = k;
         }
     }
+    // groups of one sphere (the big ones, mostly) as bitmap bits: bit 63 - N of half h is group 16 h + (N & 15) + 32 (N >> 4)
+    // (rt_scan.h, next_candidate); only meaningful while the groups ARE the filter's top level (<= 128 of them)
+    L.singleMask[0] = L.singleMask[1] = 0ull;
+    if (L.nGroups <= 128u)
+        for (uint32_t gi = 0; gi < L.nGroups; ++gi)
+            if (groups[gi].size() == 1) {
+                const uint32_t N = (gi & 15u) + 16u * (gi >> 5);
+                L.singleMask[(gi >> 4) & 1u] |= 0x8000000000000000ull >> N;
+            }
     L.leaf.assign(L.scan.size(), BoundOf(sp, {}, nullptr, rtd::kMarginKLeaf));  // padding entries are never candidates
     for (size_t e = 0; e < L.orig.size(); ++e)
         if (L.orig[e] != 0xffffffffu) L.leaf[e] = BoundOf(sp, {L.orig[e]}, nullptr, rtd::kMarginKLeaf);
@@ -1062,6 +1072,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
         b.level_cnt[k] = L.levelCnt[k];
     }
     b.bound_norm = L.boundNorm;
+    b.single_mask[0] = std::getenv("RT_SINGLE_DIRECT") && std::atoi(std::getenv("RT_SINGLE_DIRECT")) == 0 ? 0ull : L.singleMask[0];
+    b.single_mask[1] = std::getenv("RT_SINGLE_DIRECT") && std::atoi(std::getenv("RT_SINGLE_DIRECT")) == 0 ? 0ull : L.singleMask[1];
     b.radius = ctx->radius.ptr;
     b.mats = ctx->mats.ptr;
     b.n = n;

@@ -336,8 +336,8 @@ RT_DEV bool next_candidate(unsigned long long& cur, unsigned long long& nxt, uin
 template <bool kTree>
 RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restrict__ leaf, const uint32_t* __restrict__ orig,
                            const float* __restrict__ ops, uint32_t nTiles,
-                           uint32_t nTop, const float4* __restrict__ tree, const uint32_t* levelOff, uint32_t nLevels, float boundNorm, V3 o,
-                           V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand, uint32_t lane, unsigned long long* dbg) {
+                           uint32_t nTop, const float4* __restrict__ tree, const uint32_t* levelOff, uint32_t nLevels, float boundNorm,
+                           const unsigned long long* singleMask, V3 o, V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand, uint32_t lane, unsigned long long* dbg) {
     const float a = dot3(d, d);
     tmin = __builtin_inff();
     idx = -1;
@@ -440,6 +440,31 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
         best[lane] = ~0ull;
         wave_lds_handoff();
         uint32_t cntB = 0;
+        {   // Candidate groups of ONE sphere (the floor, the big spheres: a third of all candidates) skip the sphere-level filter:
+            // its only finding would be the sliver between the two margins, and an exact slot costs no more than a filter slot.
+            const unsigned long long sCur = cur & singleMask[0], sNxt = nxt & singleMask[1];
+            const uint32_t nS = (uint32_t)(__popcll(sCur) + __popcll(sNxt));
+            const uint32_t inclS = wave_inclusive_sum(nS);
+            const uint32_t totalS = (uint32_t)__builtin_amdgcn_readlane((int)inclS, 63);
+            if (totalS != 0u && totalS <= kPoolB - 4u * kWaveSize) {  // (more than that: they take the ordinary way)
+                cur &= ~sCur;
+                nxt &= ~sNxt;
+                uint16_t* wp = poolB + (inclS - nS);
+                const uint32_t tag = lane << 10;
+                unsigned long long m0 = sCur, m1 = sNxt;
+                while (m0 != 0ull) {
+                    const uint32_t N = (uint32_t)__builtin_clzll(m0);
+                    m0 &= ~(0x8000000000000000ull >> N);
+                    *wp++ = (uint16_t)(tag | (4u * (N + (N & 48u))));
+                }
+                while (m1 != 0ull) {
+                    const uint32_t N = (uint32_t)__builtin_clzll(m1);
+                    m1 &= ~(0x8000000000000000ull >> N);
+                    *wp++ = (uint16_t)(tag | (4u * (16u + N + (N & 48u))));
+                }
+                cntB = totalS;
+            }
+        }
         const uint32_t nMine = (uint32_t)(__popcll(cur) + __popcll(nxt));
         bool pending = nMine != 0u;
         RT_STAMP(ta0);
