@@ -573,6 +573,9 @@ static void QueueShards(rtd::TraceParams& tp, uint32_t wavesLaunched, uint32_t q
 // (tp.ctl etc. filled by the caller; the queue cursor lives in tp.ctl and is reset by the preparation kernel).
 static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     tp.shard_heads = ctx->queue.ptr;
+    tp.fd_tile = rtd::make_fastdiv(tp.spp_pass ? 64u * tp.spp_pass : 1u);  // path_coordinates' divisors (rt_params.h, FastDiv)
+    tp.fd_w = rtd::make_fastdiv(tp.W ? tp.W : 1u);
+    tp.fd_rows = rtd::make_fastdiv(tp.rs.block_rows ? tp.rs.block_rows : 1u);
     tp.mats_in_lds = ctx->matsInLds ? 1u : 0u;
     const size_t lds = LdsBytesFor(tp.n, tp.n_padded, ctx->matsInLds);
     if (tp.n_padded >= 65536) return Fail(RT_ERR_INVALID_ARG, "scenes beyond 65,000 spheres are not supported by the 16-bit candidate lists");

@@ -59,7 +59,7 @@ RT_DEV void path_coordinates(const TraceParams& p, uint32_t q, uint32_t& i, uint
         // so that the 51-segment paths are not the last ones a launch starts; the partial tile stays last.
         const uint32_t tileSpan = 64u * p.spp_pass;
         const uint32_t nFull = p.npix_local >> 6;
-        const uint32_t tileW = q / tileSpan;
+        const uint32_t tileW = fastdiv(q, p.fd_tile);
         uint32_t pl, k;
         slot = q;
         if (tileW < nFull) {
@@ -75,9 +75,9 @@ RT_DEV void path_coordinates(const TraceParams& p, uint32_t q, uint32_t& i, uint
             pl = (nFull << 6) + (rem - k * wl);
         }
         s = p.s0 + k;
-        const uint32_t lr = pl / p.W;
+        const uint32_t lr = fastdiv(pl, p.fd_w);
         i = pl - lr * p.W;
-        j = rowset_global_row(p.rs, lr);
+        j = rowset_global_row(p.rs, lr, p.fd_rows);
         slot += p.sample_base;  // the call's region of the sample ring (0 without frame pipelining)
     }
 }

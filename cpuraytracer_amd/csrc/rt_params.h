@@ -61,6 +61,30 @@ constexpr uint32_t kQueueShards = 8;
 #endif
 constexpr uint32_t kShardStrideWords = RT_SHARD_STRIDE_WORDS;  // distance of the cursors in 32-bit words
 
+// n / d for a divisor fixed per launch, without the ~28-operation expansion of a 32-bit division (Granlund & Montgomery,
+// "Division by invariant integers using multiplication", unsigned case): with l = ceil(log2 d) and
+// m = floor(2^32 (2^l - d) / d) + 1, t = mulhi(m, n) and q = (t + ((n - t) >> min(l, 1))) >> max(l - 1, 0) for every
+// 32-bit n.  Five operations; a prepared path needs three such quotients (tile, row, row block).
+struct FastDiv {
+    uint32_t m, sh;  // sh = sh1 | sh2 << 8
+};
+RT_DEV FastDiv make_fastdiv(uint32_t d) {
+    uint32_t l = 0;
+    while (l < 32u && (1ull << l) < (unsigned long long)d) ++l;
+    FastDiv f;
+    f.m = (uint32_t)((((1ull << l) - (unsigned long long)d) << 32) / (unsigned long long)d + 1ull);
+    f.sh = (l < 1u ? l : 1u) | ((l > 0u ? l - 1u : 0u) << 8);
+    return f;
+}
+RT_DEV uint32_t fastdiv(uint32_t n, FastDiv f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t t = __umulhi(f.m, n);
+#else
+    const uint32_t t = (uint32_t)(((unsigned long long)f.m * (unsigned long long)n) >> 32);
+#endif
+    return (t + ((n - t) >> (f.sh & 255u))) >> (f.sh >> 8);
+}
+
 struct ContEntry {
     float4 a, b, c, d, e;  // ro.xyz rd.x | rd.yz thr.xy | thr.z rad.xyz | xoshiro s0..s3 | slot, depth, region sequence & 255, traversals
     float4 f, g;           // a lane waiting for its shadow scan (far hit point): pend.xyz nextDir.x | nextDir.yz, state and flags, -
@@ -142,6 +166,7 @@ struct TraceParams {
     uint32_t static_blocks;     // blocks every wave owns without asking (block index = wave index)
     uint32_t dyn_begin, dyn_blocks;  // the shards' part of the work order: first path and number of blocks
     uint32_t sample_base;       // first 12-byte slot of this call's region in the sample ring (0 without pipelining)
+    FastDiv fd_tile, fd_w, fd_rows;  // division by 64 * spp_pass, W and rs.block_rows (set per launch)
     uint32_t ray_cache_off16;  // float4 offset of the per-wave prepared-path caches in dynamic LDS, 0 = no cache
     uint32_t* shard_heads;      // [kQueueShards][kShardStrideWords]: [k][0] = cursor of queue shard k (blocks claimed from it; zeroed before launch)
     unsigned long long* counters;  // [0] traversals, [1] segments
@@ -186,6 +211,11 @@ RT_DEV void fill_consts(const TraceParams& p, SceneConsts& k) {
 }
 
 // --------------------------------------------------------------------------- row sets
+RT_DEV uint32_t rowset_global_row(const rt_rowset& rs, uint32_t lr, FastDiv byBlockRows) {
+    const uint32_t lb = fastdiv(lr, byBlockRows);
+    const uint32_t k = lr - lb * rs.block_rows;
+    return rs.first_row + (lb * rs.nshards + rs.shard) * rs.block_rows + k;
+}
 RT_DEV uint32_t rowset_global_row(const rt_rowset& rs, uint32_t lr) {
     const uint32_t lb = lr / rs.block_rows;
     const uint32_t k = lr - lb * rs.block_rows;

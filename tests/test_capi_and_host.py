@@ -146,3 +146,25 @@ def test_clustered_layout_is_a_partition_with_enclosing_bounds(built, oracle, na
         small = [g for g in range(orig.shape[0]) if (orig[g] != 0xFFFFFFFF).sum() > 1]
         Rs = [np.sqrt(float(bounds[g, :3].astype(np.float64) @ bounds[g, :3].astype(np.float64)) - float(bounds[g, 3])) for g in small]
         assert max(Rs) < 2.2
+
+
+def test_invariant_division_by_multiplication_is_exact():
+    """rt_params.h FastDiv (the trace kernel's path index -> tile / row / row block): the Granlund-Montgomery formula,
+    restated here, equals n // d for every 32-bit n; the device code itself is covered by every image parity test (a wrong
+    quotient moves a path to another pixel)."""
+    def make(d):
+        l = 0
+        while l < 32 and (1 << l) < d:
+            l += 1
+        return ((((1 << l) - d) << 32) // d + 1) & 0xffffffff, min(l, 1), max(l - 1, 0)
+    rng = np.random.default_rng(5)
+    divisors = [1, 2, 3, 5, 7, 64, 1200, 1920, 4096, 8192, 64 * 128, 64 * 1024, 65535, 65536, 2**31 - 1, 2**31, 2**31 + 1, 2**32 - 1]
+    divisors += [int(x) for x in rng.integers(1, 2**32, 200)] + [int(x) for x in rng.integers(1, 2**16, 200)]
+    for d in divisors:
+        m, s1, s2 = make(d)
+        n = np.concatenate([rng.integers(0, 2**32, 20000, dtype=np.uint64),
+                            np.array([0, 1, d - 1, d, min(d + 1, 2**32 - 1), min(2 * d, 2**32 - 1), 2**32 - 1, 2**31], dtype=np.uint64)])
+        t = (n * np.uint64(m)) >> np.uint64(32)
+        q = ((t + ((n - t) >> np.uint64(s1))) & np.uint64(0xffffffff)) >> np.uint64(s2)
+        # (t + ((n - t) >> s1)) never exceeds 32 bits for a valid magic: the mask only documents the register width
+        assert np.array_equal(q, n // np.uint64(d)), d
