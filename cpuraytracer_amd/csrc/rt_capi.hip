@@ -122,6 +122,7 @@ struct rt_ctx {
     uint32_t pipeSeq = 0;       // sequence number of the newest region
     uint32_t pipeSppCap = 0, pipeNpix = 0, pipeRing = 0;  // geometry of the ring: samples per region, pixels, regions
     uint32_t pipeInSel = 0;     // which continuation buffer the next trace kernel reads
+    uint32_t pipeCommits = 0;   // commit kernels launched since the pipeline started (FrameCtl: which entry is current)
     uint32_t pipeMaxDepth = 0;  // max_depth and seed of the running pipeline (a flush re-launches with them)
     uint64_t pipeSeed = 0;
     rtd::RegionTable pipeRegions{};
@@ -755,10 +756,10 @@ static int PipelineTraceAndCommit(rt_ctx* ctx, rtd::TraceParams& tp, uint32_t np
     tp.counters = ctx->counters.ptr;
     int rc = LaunchTrace(ctx, tp, 2);
     if (rc != RT_OK) return rc;
-    const uint32_t commitBlocks = std::min<uint32_t>((npix + 255) / 256, (uint32_t)ctx->cuCount * 2u);
-    hipLaunchKernelGGL(rtd::rt_commit_kernel, dim3(commitBlocks), dim3(256), 0, ctx->stream, ctx->ring.ptr, ctx->hdr.ptr, npix,
-                       npix * ctx->pipeSppCap, ctx->pipeRing, ctx->pipeRegions, ctx->ctl.ptr, ctx->pipeSeq);
+    hipLaunchKernelGGL(rtd::rt_commit_kernel, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, ctx->ring.ptr, ctx->hdr.ptr, npix,
+                       npix * ctx->pipeSppCap, ctx->pipeRing, ctx->pipeRegions, ctx->ctl.ptr, ctx->pipeSeq, ctx->pipeCommits);
     RT_HIP(hipGetLastError());
+    ++ctx->pipeCommits;  // the commit point is now entry pipeCommits & 1 of the control block
     ctx->pipeInSel ^= 1u;
     return RT_OK;
 }
@@ -817,8 +818,9 @@ static int PipelineRender(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uin
         if ((rc = ctx->ctl.Reserve(1)) != RT_OK) return rc;
         rtd::FrameCtl init{};
         init.oldest_open = 0xffffffffu;
-        init.committed_seq = ctx->pipeSeq;              // everything up to here is in the strip already
-        init.committed_samples = ctx->accumulated;
+        init.committed_seq[0] = ctx->pipeSeq;              // everything up to here is in the strip already
+        init.committed_samples[0] = ctx->accumulated;
+        ctx->pipeCommits = 0;
         RT_HIP(hipMemcpyAsync(ctx->ctl.ptr, &init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
         RT_HIP(hipStreamSynchronize(ctx->stream));       // `init` is a stack object; once per pipeline start
         ctx->pipeOpen = true;
@@ -1116,7 +1118,7 @@ int rt_committed_samples(rt_ctx* ctx, uint32_t* out) {
     if (ctx->pipeOpen) {
         rtd::FrameCtl c{};
         RT_HIP(hipMemcpy(&c, ctx->ctl.ptr, sizeof(c), hipMemcpyDeviceToHost));
-        *out = c.committed_samples;
+        *out = c.committed_samples[ctx->pipeCommits & 1u];
     }
     return RT_OK;
 }
@@ -1306,7 +1308,7 @@ int rt_resolve(rt_ctx* ctx, uint32_t n_samples) {
     const uint32_t npix = ctx->W * ctx->rows;
     RT_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     // with frames in flight the strip holds FrameCtl::committed_samples samples, a number only the device knows
-    const uint32_t* devCount = (ctx->pipeOpen && n_samples == 0) ? &ctx->ctl.ptr->committed_samples : nullptr;
+    const uint32_t* devCount = (ctx->pipeOpen && n_samples == 0) ? &ctx->ctl.ptr->committed_samples[ctx->pipeCommits & 1u] : nullptr;
     hipLaunchKernelGGL(rtd::rt_resolve_kernel, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, ctx->hdr.ptr, ctx->ldr.ptr, npix, n,
                        devCount);
     RT_HIP(hipGetLastError());

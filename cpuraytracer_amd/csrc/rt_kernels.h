@@ -881,12 +881,19 @@ struct RegionTable {
 };
 __global__ void __launch_bounds__(256) rt_commit_kernel(const float* __restrict__ ring, float* __restrict__ hdr, uint32_t npix,
                                                         uint32_t regionEntries, uint32_t nRing, RegionTable rt, FrameCtl* ctl,
-                                                        uint32_t newestSeq) {
-    const uint32_t committed = ctl->committed_seq, open = ctl->oldest_open;
+                                                        uint32_t newestSeq, uint32_t commitNo) {
+    const uint32_t committed = ctl->committed_seq[commitNo & 1u], open = ctl->oldest_open;
     uint32_t limit = newestSeq;
     if (open != 0xffffffffu && open - 1u < limit) limit = open - 1u;
-    // a few hundred blocks striding over the pixels: the closing ticket is one same-address atomic per block
-    for (uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x; pix < npix && limit > committed; pix += gridDim.x * blockDim.x) {
+    if (limit < committed) limit = committed;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the other entry: nobody reads it before the next commit kernel
+        uint32_t add = 0;
+        for (uint32_t q = committed + 1u; q <= limit; ++q) add += rt.spp[q % nRing];
+        ctl->committed_seq[(commitNo + 1u) & 1u] = limit;
+        ctl->committed_samples[(commitNo + 1u) & 1u] = ctl->committed_samples[commitNo & 1u] + add;
+    }
+    if (limit == committed) return;
+    for (uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += gridDim.x * blockDim.x) {
         float r = hdr[3 * (size_t)pix], g = hdr[3 * (size_t)pix + 1], b = hdr[3 * (size_t)pix + 2];
         const uint32_t nFull = npix >> 6, tile = pix >> 6;
         const uint32_t stride = tile < nFull ? 64u : npix - (nFull << 6);
@@ -904,20 +911,6 @@ __global__ void __launch_bounds__(256) rt_commit_kernel(const float* __restrict_
         hdr[3 * (size_t)pix] = r;
         hdr[3 * (size_t)pix + 1] = g;
         hdr[3 * (size_t)pix + 2] = b;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const uint32_t t = atomicAdd(&ctl->acc_ticket, 1u);
-        if (t == gridDim.x - 1u) {
-            if (limit > committed) {
-                uint32_t add = 0;
-                for (uint32_t q = committed + 1u; q <= limit; ++q) add += rt.spp[q % nRing];
-                ctl->committed_seq = limit;
-                ctl->committed_samples += add;
-            }
-            ctl->acc_ticket = 0u;
-        }
     }
 }
 

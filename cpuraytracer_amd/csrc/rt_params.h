@@ -95,9 +95,11 @@ struct ContEntry {
 // same-line atomics per 1-spp frame, which one L2 channel serialises at ~11 ns each -- 0.3 ms per frame.)
 struct FrameCtl {            // device control block of one context's pipeline
     uint32_t oldest_open;    // min region sequence among the paths carried out of the last trace kernel (0xffffffff: none)
-    uint32_t committed_seq;  // regions with sequence <= this are in the HDR strip
-    uint32_t committed_samples;  // samples per pixel in the HDR strip
-    uint32_t acc_ticket;     // blocks of the commit kernel that have finished (the last one publishes committed_*)
+    // The commit point, twice: commit kernel number k reads entry k & 1 and its first block writes entry (k + 1) & 1, so no
+    // block can see the new value early and nothing has to wait for "the last block" (a closing ticket was one same-address
+    // atomic per block, which held the kernel to a few hundred blocks; it now runs one pixel per thread).
+    uint32_t committed_seq[2];      // regions with sequence <= this are in the HDR strip
+    uint32_t committed_samples[2];  // samples per pixel in the HDR strip
 };
 constexpr uint32_t kMaxFramesInFlight = 16;  // regions of the sample ring
 
