@@ -749,12 +749,15 @@ __global__ void __launch_bounds__(256) rt_raygen_tables_kernel(float2* jitter, u
 // the most expensive material among their first hits -- nothing, anything else, metal, glass -- and the launches of the
 // accumulation take the tiles by descending class: the sky, whose paths end after one scan, comes last.  Results do not
 // depend on the order (every path has its own slot and stream); only the schedule does.
-constexpr uint32_t kPilotsPerTile = 3;
+#ifndef RT_PILOTS_PER_TILE
+#define RT_PILOTS_PER_TILE 3
+#endif
+constexpr uint32_t kPilotsPerTile = RT_PILOTS_PER_TILE;  // evenly spaced over the tile's 64 pixels, both ends included
 __global__ void __launch_bounds__(256) rt_pilot_rays_kernel(const TraceParams p, uint32_t nFull, float* rays) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nFull * kPilotsPerTile) return;
     const uint32_t tile = t / kPilotsPerTile, which = t - tile * kPilotsPerTile;
-    const uint32_t pl = (tile << 6) + (which == 0u ? 0u : (which == 1u ? 32u : 63u));
+    const uint32_t pl = (tile << 6) + (which * 63u + (kPilotsPerTile - 1u) / 2u) / (kPilotsPerTile - 1u);
     const uint32_t lr = pl / p.W;
     V3 o, d;
     gen_primary_ray(p, pl - lr * p.W, rowset_global_row(p.rs, lr), 1u, o, d);
