@@ -229,10 +229,10 @@ RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint1
     const bool aOk = false;
     const float yaL = 0.f;
 #endif
-#define RT_CONSIDER(ID)                                                              \
+#define RT_CONSIDER(ID, SPH)                                                         \
     {                                                                                \
         const uint32_t id_ = (ID);                                                   \
-        const float4 S = tab[id_];                                                   \
+        const float4 S = (SPH);                                                      \
         const float ocx = pos.x - S.x;                                               \
         const float ocy = pos.y - S.y;                                               \
         const float ocz = pos.z - S.z;                                               \
@@ -248,15 +248,32 @@ RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint1
             }                                                                        \
         }                                                                            \
     }
-    for (uint32_t k = 0; k < p.sg_nglobal; ++k) RT_CONSIDER(glob[k])
+    // two entries per round: both ids, then both spheres, are requested together -- one entry at a time costs two LDS round
+    // trips back to back (id, then sphere) per entry with nothing to do in between
+#define RT_WALK(LIST, FIRST, END)                                                    \
+    {                                                                                \
+        uint32_t e_ = (FIRST);                                                       \
+        const uint32_t e1_ = (END);                                                  \
+        for (; e_ + 2u <= e1_; e_ += 2u) {                                           \
+            const uint32_t idA = (LIST)[e_], idB = (LIST)[e_ + 1u];                  \
+            const float4 SA = tab[idA], SB = tab[idB];                               \
+            RT_CONSIDER(idA, SA)                                                     \
+            RT_CONSIDER(idB, SB)                                                     \
+        }                                                                            \
+        if (e_ < e1_) {                                                              \
+            const uint32_t idA = (LIST)[e_];                                         \
+            RT_CONSIDER(idA, tab[idA])                                               \
+        }                                                                            \
+    }
+    RT_WALK(glob, 0u, p.sg_nglobal)
     const float u = dot3(pos, v3(p.sg_e1[0], p.sg_e1[1], p.sg_e1[2]));
     const float v = dot3(pos, v3(p.sg_e2[0], p.sg_e2[1], p.sg_e2[2]));
     const float fx = (u - p.sg_u0) * p.sg_inv_cell, fy = (v - p.sg_v0) * p.sg_inv_cell;
     if (fx >= 0.f && fy >= 0.f && fx < (float)p.sg_nx && fy < (float)p.sg_ny) {
         const uint32_t c = (uint32_t)fy * p.sg_nx + (uint32_t)fx;
-        const uint32_t e1 = cellStart[c + 1];
-        for (uint32_t e = cellStart[c]; e < e1; ++e) RT_CONSIDER(entries[e])
+        RT_WALK(entries, (uint32_t)cellStart[c], (uint32_t)cellStart[c + 1])
     }
+#undef RT_WALK
 #undef RT_CONSIDER
     while (nq > 0u && !occluded) {
         const uint32_t id = (uint32_t)(queue & 0xffffull);
