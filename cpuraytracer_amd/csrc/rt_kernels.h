@@ -242,6 +242,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     static_assert(!kHitLds || kScan != 0, "kHitLds belongs to the matrix-core variants");
 #ifdef RT_TIMELINE
     const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz; diagnostic build only
+    uint32_t tlCarriedIn = 0;
 #endif
     extern __shared__ float4 smem[];
     // [0, kConstBytes): the scene constants; then the per-wave regions; then the tables
@@ -309,6 +310,9 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     if (kCarry) {
         // the wave's own carried paths (rt_params.h): no cursor, no atomics
         const uint32_t nIn = p.cont_in_n[gwave];
+#ifdef RT_TIMELINE
+        tlCarriedIn = nIn;
+#endif
         if (lane < nIn) {
             const ContEntry* e = p.cont_in + ((size_t)gwave * kWaveSize + lane);
             const float4 A = e->a, B = e->b, Cc = e->c, D = e->d, E = e->e;
@@ -491,14 +495,6 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
             // kernel to kernel untouched until the age limit makes some wave run their whole tail)
             const bool nothingToStart = queueEmpty && cachePos == cacheCnt && p.carry != 0u && itersHere >= p.min_iters;
             const bool carriable = state == kIdle || ((p.region_seq - seq8) & 255u) < p.max_carry_age;
-#ifdef RT_TIMELINE
-            if (lane == 0 && itersHere > 14u) {
-                if (!queueEmpty) atomicAdd(&g_tl[8], 1ull);
-                else if (cachePos != cacheCnt) atomicAdd(&g_tl[9], 1ull);
-                else if (__ballot(!carriable) != 0ull) atomicAdd(&g_tl[10], 1ull);
-                else atomicAdd(&g_tl[11], 1ull);
-            }
-#endif
             if (nothingToStart && __ballot(!carriable) == 0ull) {
                 const uint64_t liveMask = __ballot(state != kIdle);
                 carried = (uint32_t)__popcll(liveMask);
@@ -661,29 +657,12 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
 #ifdef RT_TIMELINE
     if (lane == 0) {
         const unsigned long long tl2 = __builtin_amdgcn_s_memrealtime();
-        if (!kCarry) {
-            // one 64-byte record per wave, plain stores: shared counters here would be 4,096 x n same-line atomics at ~11 ns
-            // each when the waves leave together -- the instrument would make the tail it is meant to measure
-            if (gwave < 4096u) {
-                unsigned long long* w = g_tlWave + 8u * gwave;
-                w[0] = tl0; w[1] = tlDrain != 0ull ? tlDrain : tl2; w[2] = tl2; w[3] = tlBlocks; w[4] = tlLastBlock; w[5] = tlLastClaim;
-                w[6] = tlIters; w[7] = drainIters;
-            }
-        } else {  // g_tl: [0] min start, [1] max staged, [2] max loop exit, [3] sum of (exit - start), [4] waves, [5] sum iterations
-            atomicMin(&g_tl[0], tl0);
-            atomicMax(&g_tl[1], tl1);
-            atomicMax(&g_tl[2], tl2);
-            atomicAdd(&g_tl[3], tl2 - tl0);
-            atomicAdd(&g_tl[4], 1ull);
-            atomicAdd(&g_tl[5], (unsigned long long)itersHere);
-            atomicMin(&g_tl[6], tl1);
-            atomicMin(&g_tl[7], tl2);
-            {
-                const unsigned long long b = (tl2 - tl0) / 2500ull;
-                atomicAdd(&g_tlHist[b < 1023ull ? (unsigned)b : 1023u], 1u);
-            }
-            atomicMax(&g_tl[12], (unsigned long long)itersHere);
-            if (itersHere > 14u) atomicAdd(&g_tl[13], 1ull);
+        // one 64-byte record per wave, plain stores: shared counters here would be 4,096 x n same-line atomics at ~11 ns
+        // each when the waves leave together -- the instrument would make the tail it is meant to measure
+        if (gwave < 4096u) {
+            unsigned long long* w = g_tlWave + 8u * gwave;
+            w[0] = tl0; w[1] = kCarry ? tl1 : (tlDrain != 0ull ? tlDrain : tl2); w[2] = tl2; w[3] = tlBlocks; w[4] = kCarry ? carried : tlLastBlock;
+            w[5] = kCarry ? ((tlLastClaim - tl0) << 8 | (unsigned long long)tlCarriedIn) : tlLastClaim; w[6] = tlIters; w[7] = drainIters;
         }
     }
 #endif

@@ -5,11 +5,14 @@ their 51-iteration tail) and checks that the frames equal one N-spp call bit for
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+from cpuraytracer_amd import _capi
+if os.environ.get("RT_HIP_LIB"):  # A/B runs against another build of the library (tool only)
+    _capi.LIB_PATH = os.path.abspath(os.environ["RT_HIP_LIB"])
 from cpuraytracer_amd import HipRenderer, scenes
 W, H, N = 1200, 800, 256
 sc = scenes.build_scene("cover", 1, W, H)
 one = HipRenderer(0); one.upload(sc); one.render(W, H, 1, N + 1, 50, 1); one.resolve(); h1, _ = one.download()
-for depth in (0, 2, 4, 8):
+for depth in [int(x) for x in os.environ.get("RT_DEPTHS", "0,2,4,8").split(",")]:
     r = HipRenderer(0); r.upload(sc)
     r.set_frame_pipelining(depth)
     r.render(W, H, 1, 2, 50, 1, stats=False); r.synchronize()   # warm-up (buffers, LDS attribute)
