@@ -804,6 +804,8 @@ def _render_with_env(monkeypatch, env, sc, W, H, s1, depth=50, seed=1):
     {"RT_SCAN": "valu", "RT_BLOCKS_PER_CU": "2", "RT_SHADOW_GRID": "0"},
     {"RT_SHADOW_GRID": "0", "RT_MATS_LDS": "0", "RT_RAY_CACHE": "0", "RT_BLOCK_THREADS": "512"},
     {"RT_TILE_ORDER": "0"},                                    # tiles in image order instead of expensive-first
+    {"RT_SINGLE_DIRECT": "0"},                                 # one-sphere groups through the sphere-level filter like the rest
+    {"RT_QUEUE_BLOCK": "256", "RT_QUEUE_STATIC": "0"},         # queue geometry: bigger blocks, nothing static
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_launch_and_layout_knobs_give_the_same_bits(hip, scenes_mod, monkeypatch, env):
     W, H, s1 = 161, 103, 5  # ragged: the last tile of the sample buffer is 9 pixels wide
