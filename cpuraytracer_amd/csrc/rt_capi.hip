@@ -112,6 +112,8 @@ struct rt_ctx {
     // work order of the tiles (BuildTileOrder): valid for the running accumulation's strip
     bool useTileOrder = true;  // RT_TILE_ORDER=0 keeps the image order
     bool tileOrderValid = false;
+    uint32_t tileW = 0, tileH = 0;  // ... and the image and strip it was built for (with the scene, all it depends on)
+    rt_rowset tileRs{};
     DevBuf<float> pilotRays, pilotHits;
     DevBuf<uint32_t> tileOrder, matType;
     DevBuf<uint8_t> tileClass;
@@ -702,6 +704,9 @@ static int LaunchClosest(rt_ctx* ctx, const float* dRays, uint32_t n, float* dOu
 // Work order of the full tiles for the accumulation that is starting (rt_kernels.h, rt_tile_order_kernel): three pilot rays per
 // tile through the production scan, then a stable sort by the most expensive first-hit material.  All on the stream, no host wait.
 static int BuildTileOrder(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t npix) {
+    // the order is a function of the scene (camera included), the image size and the strip: a new accumulation of the same
+    // picture -- a progressive restart, the next frame of a turntable with an unchanged scene -- keeps the one it has
+    if (ctx->tileOrderValid && ctx->tileW == W && ctx->tileH == H && std::memcmp(&ctx->tileRs, &rs, sizeof(rs)) == 0) return RT_OK;
     ctx->tileOrderValid = false;
     const uint32_t nFull = npix >> 6;
     if (!ctx->useTileOrder || nFull < 2u * (uint32_t)ctx->cuCount) return RT_OK;  // too little work for the order to matter
@@ -727,6 +732,9 @@ static int BuildTileOrder(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uin
     hipLaunchKernelGGL(rtd::rt_tile_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->tileClass.ptr, nFull, ctx->tileOrder.ptr);
     RT_HIP(hipGetLastError());
     ctx->tileOrderValid = true;
+    ctx->tileW = W;
+    ctx->tileH = H;
+    ctx->tileRs = rs;
     return RT_OK;
 }
 
@@ -1128,6 +1136,7 @@ int rt_set_sampler(rt_ctx* ctx, uint32_t flags) {
     if (flags != ctx->sampler) {
         ctx->accumulated = 0;  // samples of two mappings do not mix: the next rt_render starts over
         PipelineDrop(ctx);
+        ctx->tileOrderValid = false;  // the pilot rays use the lens mapping
     }
     ctx->sampler = flags;
     return RT_OK;

@@ -53,7 +53,7 @@ RT_DEV void path_coordinates(const TraceParams& p, uint32_t q, uint32_t& i, uint
         slot = q;
     } else {
         // storage order = [tile of 64 local pixels][sample of the pass][pixel in tile] (the last tile is as wide as the
-        // pixels left): a wave's block of 256 consecutive work-items is four sample planes of one tile, so its 12-byte
+        // pixels left): a wave's block of 128 consecutive work-items is two sample planes of one tile, so its 12-byte
         // results fill whole cache lines, and rt_accumulate_kernel reads 768 contiguous bytes per plane.  The WORK order
         // is the same with the full tiles permuted by tile_order (expensive tiles first, sky last: rt_tile_order_kernel),
         // so that the 51-segment paths are not the last ones a launch starts; the partial tile stays last.
