@@ -250,7 +250,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share GPUs over gloo, not a measurement)" if rehearsal else ""),
             "config": {"workload": "%s scene (%d spheres, scene seed %d) %dx%d spp=%d depth=%d%s, render seed %d; "
-                                   "rows sharded cyclically over %d GPU(s) in 4-row blocks, RCCL gather of strips to rank 0"
+                                   "rows sharded cyclically (row j to rank j mod N) over %d GPU(s), RCCL gather of strips to rank 0"
                                    % (cfg["scene"], n_spheres, SCENE_SEED, W_IMG, H_IMG, spp, DEPTH,
                                       (" aperture=%.1f" % cfg["aperture"]) if cfg["aperture"] >= 0 else "", RENDER_SEED, N),
                        "name": args.config, "n_spheres": n_spheres, "spp": spp, "spp_per_gpu": SPP_PER_GPU, "samples_per_step": total_samples,

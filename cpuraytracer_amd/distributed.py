@@ -1,16 +1,16 @@
 """Multi-GPU layer: one process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI).
 
-The path shards by image rows: rank r renders the 4-row blocks b with
-b % world == r of the SAME image (cyclic, because cost is strongly row dependent), every rank holds
+The path shards by image rows: rank r renders the rows j with j % world == r of the SAME
+image (cyclic, because cost is strongly row dependent; single rows, because cost also grows steadily towards the
+bottom of the picture: with 4-row blocks the rank that always got the lowest rows of each band had 2 % more
+work than the mean, with single rows 0.5 % -- tools/shard_balance_probe.py), every rank holds
 the whole (tiny) scene, and the only exchange step is one gather of the finished strips to rank 0,
 which de-interleaves them.  Each pixel depends only on (global pixel id, s, seed), so the assembled
 image is byte-identical to the single-GPU image.  No other collective exists on the path.
 """
 import numpy as np
 
-from ._capi import RtRowset
-
-BLOCK_ROWS = 4
+from ._capi import BLOCK_ROWS, RtRowset
 
 
 def shard_rowset(H, rank, world, block_rows=BLOCK_ROWS):

@@ -72,20 +72,21 @@ def test_rowset_arithmetic_matches_oracle_and_python(built, oracle):
     from cpuraytracer_amd import _capi, distributed as D
     L = _capi.load()
     O = oracle.lib()
-    for H in (1, 4, 50, 100, 800, 1080):
-        for world in (1, 2, 3, 4, 8):
-            seen = np.zeros(H, dtype=int)
-            for rank in range(world):
-                rs = _capi.cyclic_rows(H, rank, world)
-                n = L.rt_rowset_local_rows(rs)
-                assert n == O.orc_rowset_local_rows(oracle.RtRowset(0, H, 4, rank, world)) == D.local_rows(H, rank, world)
-                for lr in range(n):
-                    j = L.rt_rowset_global_row(rs, lr)
-                    assert j == D.global_row(lr, rank, world) == O.orc_rowset_global_row(oracle.RtRowset(0, H, 4, rank, world), lr)
-                    seen[j] += 1
-            assert (seen == 1).all()
+    assert D.BLOCK_ROWS == _capi.BLOCK_ROWS
+    for br in (1, 4):  # the partition's default (single rows) and round 1's 4-row blocks
+        for H in (1, 4, 50, 100, 800, 1080):
+            for world in (1, 2, 3, 4, 8):
+                seen = np.zeros(H, dtype=int)
+                for rank in range(world):
+                    rs = _capi.cyclic_rows(H, rank, world, br)
+                    n = L.rt_rowset_local_rows(rs)
+                    assert n == O.orc_rowset_local_rows(oracle.RtRowset(0, H, br, rank, world)) == D.local_rows(H, rank, world, br)
+                    for lr in range(n):
+                        j = L.rt_rowset_global_row(rs, lr)
+                        assert j == D.global_row(lr, rank, world, br) == O.orc_rowset_global_row(oracle.RtRowset(0, H, br, rank, world), lr)
+                        seen[j] += 1
+                assert (seen == 1).all()  # a partition of the rows
     assert L.rt_rowset_local_rows(_capi.RtRowset(0, 8, 0, 0, 1)) == 0  # degenerate: block_rows 0
-    assert L.rt_rowset_local_rows(_capi.RtRowset(0, 8, 4, 2, 2)) == 0  # shard >= nshards
 
 
 def test_assemble_deinterleaves(built):
