@@ -185,8 +185,7 @@ def main():
     r.upload(sc)  # scene resident in HBM before the timed region
     rs = D.shard_rowset(H_IMG, rank, N)
     rows = D.local_rows(H_IMG, rank, N)
-    hdr_strip = torch.empty((rows, W_IMG, 3), dtype=torch.float32, device="cuda")
-    ldr_strip = torch.empty((rows, W_IMG, 3), dtype=torch.uint8, device="cuda")
+    xch = D.StripExchange(H_IMG, W_IMG, rank, N, "cuda")  # HDR + LDR strip of this rank in one buffer: one gather per step
 
     kernel_ms, trav, last = [], [], None
 
@@ -194,14 +193,10 @@ def main():
         nonlocal last
         st = r.render(W_IMG, H_IMG, 1, 1 + spp, DEPTH, RENDER_SEED, rowset=rs)
         r.resolve()
-        r.copy_to_device(hdr_strip.data_ptr(), ldr_strip.data_ptr())
+        r.copy_to_device(xch.hdr.data_ptr(), xch.ldr.data_ptr())
         if rehearsal:
             r.synchronize()
-            parts_h = D.gather_strip(hdr_strip.cpu(), H_IMG, rank, N)
-            parts_l = D.gather_strip(ldr_strip.cpu(), H_IMG, rank, N)
-        else:
-            parts_h = D.gather_strip(hdr_strip, H_IMG, rank, N)  # RCCL gather of tile rows (no-op at N = 1)
-            parts_l = D.gather_strip(ldr_strip, H_IMG, rank, N)
+        parts_h, parts_l = xch.gather(through_host=rehearsal)  # RCCL gather of the strips (no-op at N = 1)
         last = (st, parts_h, parts_l)
         return st
 

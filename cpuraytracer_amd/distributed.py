@@ -61,3 +61,36 @@ def gather_strip(strip, H, rank, world, dst=0, group=None):
     out = [torch.empty_like(strip) for _ in range(world)] if rank == dst else None
     dist.gather(strip, out, dst=dst, group=group)
     return out
+
+
+class StripExchange:
+    """One buffer per rank holding its HDR strip (float32) followed by its LDR strip (uint8), both padded to the largest shard,
+    and ONE gather per step for the two of them (two collectives of a megabyte each cost twice the launch and rendezvous)."""
+
+    def __init__(self, H, W, rank, world, device):
+        import torch
+        self.H, self.W, self.rank, self.world = H, W, rank, world
+        self.rows = local_rows(H, rank, world)
+        self.rows_max = max_local_rows(H, world)
+        self.hdr_bytes = self.rows_max * W * 3 * 4
+        self.buf = torch.zeros(self.hdr_bytes + self.rows_max * W * 3, dtype=torch.uint8, device=device)
+        self.hdr = self.buf[:self.hdr_bytes].view(torch.float32).view(self.rows_max, W, 3)
+        self.ldr = self.buf[self.hdr_bytes:].view(self.rows_max, W, 3)
+        self.out = [torch.empty_like(self.buf) for _ in range(world)] if (rank == 0 and world > 1) else None
+
+    def gather(self, through_host=False):
+        """-> (hdr parts, ldr parts) on rank 0, (None, None) elsewhere.  through_host: CPU tensors over gloo (rehearsal)."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return [self.hdr], [self.ldr]
+        if through_host:
+            src = self.buf.cpu()
+            out = [torch.empty_like(src) for _ in range(self.world)] if self.rank == 0 else None
+        else:
+            src, out = self.buf, self.out
+        dist.gather(src, out, dst=0)
+        if self.rank != 0:
+            return None, None
+        W, rm, hb = self.W, self.rows_max, self.hdr_bytes
+        return ([o[:hb].view(torch.float32).view(rm, W, 3) for o in out], [o[hb:].view(rm, W, 3) for o in out])

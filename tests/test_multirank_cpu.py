@@ -37,10 +37,21 @@ def _worker(rank, world, port, H, W, out_path):
         hdr, _ = orc.download()
         assert hdr.shape[0] == D.local_rows(H, rank, world)
         parts = D.gather_strip(torch.from_numpy(hdr), H, rank, world)
+        # bench.py's exchange: HDR and LDR strip in one buffer, one gather for both (ragged heights: padded to the largest shard)
+        orc.resolve()
+        hdr2, ldr2 = orc.download()
+        xch = D.StripExchange(H, W, rank, world, "cpu")
+        xch.hdr[:hdr2.shape[0]] = torch.from_numpy(hdr2)
+        xch.ldr[:ldr2.shape[0]] = torch.from_numpy(ldr2)
+        ph, pl = xch.gather(through_host=True)
         dist.barrier()
         if rank == 0:
             full = D.assemble([p.numpy() for p in parts], H, world)
             np.save(out_path, full)
+            np.save(out_path + ".xh.npy", D.assemble([p.numpy() for p in ph], H, world))
+            np.save(out_path + ".xl.npy", D.assemble([p.numpy() for p in pl], H, world))
+        else:
+            assert ph is None and pl is None
     finally:
         dist.destroy_process_group()
 
@@ -56,5 +67,8 @@ def test_sharded_render_gathers_to_the_single_rank_image(built, oracle, tmp_path
     orc = oracle.Oracle()
     orc.upload(sc)
     orc.render(W, H, 1, 3, 8, 1)
-    want, _ = orc.download()
+    orc.resolve()
+    want, want_ldr = orc.download()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(np.load(out + ".xh.npy").view(np.uint32), want.view(np.uint32))  # the one-buffer exchange: HDR ...
+    assert np.array_equal(np.load(out + ".xl.npy"), want_ldr)                              # ... and LDR
