@@ -437,7 +437,7 @@ def test_random_scenes_scaled_and_translated_differential(hip, oracle, seed, n, 
     _fuzz_case(hip, oracle, seed, n, scale, offset)
 
 
-def _fuzz_case(hip, oracle, seed, n, scale, offset):
+def _fuzz_scene(oracle, seed, n, scale, offset):
     rng = np.random.default_rng(1000 + seed)
     offset = np.asarray(offset, dtype=np.float64)
     extent = rng.choice([3.0, 12.0, 60.0])
@@ -461,6 +461,11 @@ def _fuzz_case(hip, oracle, seed, n, scale, offset):
     sc.materials["smoothness"] = np.where(types == 1, 0.0, rng.uniform(1.0, 64.0, n)).astype(np.float32)
     sc.materials["ior"] = rng.uniform(1.1, 2.4, n).astype(np.float32)
     sc.materials["luminance"] = np.where(types == 3, rng.uniform(100.0, 20000.0, n), 0.0).astype(np.float32)
+    return sc, rng
+
+
+def _fuzz_case(hip, oracle, seed, n, scale, offset):
+    sc, rng = _fuzz_scene(oracle, seed, n, scale, offset)
     hip.upload(sc)
     orc = oracle.Oracle()
     orc.upload(sc)
@@ -474,6 +479,14 @@ def _fuzz_case(hip, oracle, seed, n, scale, offset):
     assert_same(rg, ro, "per-sample radiance")
     assert np.array_equal(tg, to)
     assert np.isfinite(rg).all()
+
+
+@pytest.mark.parametrize("seed,n,W,H,spp", [(31, 60, 403, 203, 3), (32, 400, 320, 203, 2), (33, 1500, 403, 160, 2)])
+def test_random_scene_images_equal_the_oracle_render(hip, oracle, seed, n, W, H, spp):
+    """The same random scenes as WHOLE IMAGES (1,000+ tiles, so the work order from pilot rays is built; the queue, the ordered
+    accumulation and the counters are on the path): HDR strip, traversal and segment counts equal the oracle's render."""
+    sc, _ = _fuzz_scene(oracle, seed, n, 1.0, (0.0, 0.0, 0.0))
+    _assert_image_equals_oracle(hip, oracle, sc, W, H, spp, 20, seed=9 + seed)
 
 
 # ------------------------------------------- properties at BASELINE.json's full size (C2)
