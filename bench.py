@@ -44,6 +44,8 @@ CONFIGS = {
     # name: scene, W, H, spp per GPU, aperture (-1 = the scene's own), metric text, PMC summary
     "c2": dict(scene="cover", W=1200, H=800, spp=128, aperture=-1.0,
                metric="Msamples/sec (WxHxspp/s), 1200x800 cover scene spp=128 d=50", pmc="r02_pmc_summary.json"),
+    "c3": dict(scene="cover", W=1200, H=800, spp=1024, aperture=-1.0,  # BASELINE config 3's whole job on ONE GPU: one 11.8 GB pass
+               metric="Msamples/sec (WxHxspp/s), 1200x800 cover scene spp=1024 d=50", pmc="r02_pmc_summary_c3.json"),
     "c4": dict(scene="cover", W=1920, H=1080, spp=512, aperture=2.0,
                metric="Msamples/sec (WxHxspp/s), 1920x1080 cover scene aperture=2.0 spp=512 d=50", pmc="r02_pmc_summary_c4.json"),
     "c5": dict(scene="grid10k", W=4096, H=4096, spp=64, aperture=-1.0,

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
-@pytest.mark.parametrize("name", ["c2", "c4", "c5"])
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
 def test_committed_pmc_summary_belongs_to_these_kernel_sources(name):
     """tools/profile_round.sh + summarize_profile.py must be re-run after the last kernel edit of a round: bench.py withholds the
     roofline fraction when the hash recorded with the counters is not the hash of the sources the library is built from."""
@@ -23,7 +23,7 @@ def test_committed_pmc_summary_belongs_to_these_kernel_sources(name):
     assert d["kernel_sources_sha256"] == bench.kernel_sources_hash(), "profiles/%s is stale: re-profile" % cfg["pmc"]
 
 
-@pytest.mark.parametrize("name", ["c2", "c4", "c5"])
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
 def test_roofline_object_is_a_fraction_recomputable_from_the_summary(name):
     cfg = bench.CONFIGS[name]
     d = json.load(open(os.path.join(ROOT, "profiles", cfg["pmc"])))
