@@ -159,6 +159,7 @@ struct SceneLayout {
     uint32_t nGroups = 0;         // = levelCnt[0], a multiple of 4
     float boundNorm = 0.f;        // max |C| + R
     unsigned long long singleMask[2] = {0ull, 0ull};  // groups of one sphere, in the flat scan's bitmap coordinates
+    uint32_t nAlways = 0;         // hierarchy scan: leading big-sphere groups kept out of the hierarchy (tested for every ray)
 };
 
 // Conservative bounding sphere of a set of spheres, in the filter's (C, |C|^2 - Rf^2) form.
@@ -396,6 +397,16 @@ static void BuildLayout(const rt_sphere* sp, uint32_t n, uint32_t topMax, SceneL
     // level is tested by the matrix-core filter (margin K = kMarginK), the levels below it on the VALU (kMarginKValu).
     std::vector<std::vector<std::vector<uint32_t>>> levels;
     levels.push_back(groups);
+    // Hierarchy scan (more groups than the matrix-core level takes): the big spheres stay out of the bounds.  With the floor
+    // inside, node 0 of every level is a candidate for every ray and drags its siblings into the descent; tested directly, a
+    // big sphere costs one exact slot per live ray.  (At most eight; the flat scan keeps them as one-sphere groups.)
+    L.nAlways = 0;
+    if (groups.size() > topMax && std::getenv("RT_ALWAYS_BIG") == nullptr) {
+        while (L.nAlways < 8u && L.nAlways < big.size() && groups[L.nAlways].size() == 1) {
+            levels[0][L.nAlways].clear();
+            ++L.nAlways;
+        }
+    }
     while (levels.back().size() > topMax && levels.size() < rtd::kMaxLevels) {
         std::vector<std::vector<uint32_t>>& cur = levels.back();
         while (cur.size() & 3u) cur.push_back({});  // pad this level to whole parents
@@ -1089,6 +1100,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
         b.level_cnt[k] = L.levelCnt[k];
     }
     b.bound_norm = L.boundNorm;
+    b.n_always = L.nAlways;
     b.single_mask[0] = std::getenv("RT_SINGLE_DIRECT") && std::atoi(std::getenv("RT_SINGLE_DIRECT")) == 0 ? 0ull : L.singleMask[0];
     b.single_mask[1] = std::getenv("RT_SINGLE_DIRECT") && std::atoi(std::getenv("RT_SINGLE_DIRECT")) == 0 ? 0ull : L.singleMask[1];
     b.radius = ctx->radius.ptr;

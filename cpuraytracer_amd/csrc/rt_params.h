@@ -124,6 +124,8 @@ struct TraceParams {
     uint32_t mats_in_lds;      // stage the material table into LDS (else it is read through L2)
     float bound_norm;          // max over groups of |C| + R (scale of the filter's behind-the-origin threshold)
     unsigned long long single_mask[2];  // flat scan: groups of ONE sphere, as bits of the two candidate-bitmap halves (rt_scan.h)
+    uint32_t n_always;         // hierarchy scan: the first n_always groups hold one big sphere each and are NOT in the hierarchy:
+                               // every live ray tests them exactly (a floor inside the bounds makes every node above it a candidate)
     uint32_t n_padded;         // 4 * n_groups + 4
     // Exact shadow index for the (single, directional) sun: spheres binned by their footprint in the plane
     // perpendicular to the light.  Valid for hit points with |p|^2 <= sg_p0sq.

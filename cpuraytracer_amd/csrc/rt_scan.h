@@ -337,7 +337,7 @@ template <bool kTree>
 RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restrict__ leaf, const uint32_t* __restrict__ orig,
                            const float* __restrict__ ops, uint32_t nTiles,
                            uint32_t nTop, const float4* __restrict__ tree, const uint32_t* levelOff, uint32_t nLevels, float boundNorm,
-                           const unsigned long long* singleMask, V3 o, V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand, uint32_t lane, unsigned long long* dbg) {
+                           const unsigned long long* singleMask, uint32_t nAlways, V3 o, V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand, uint32_t lane, unsigned long long* dbg) {
     const float a = dot3(d, d);
     tmin = __builtin_inff();
     idx = -1;
@@ -614,6 +614,13 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
             nExact = 0;
             wave_lds_handoff();  // the exact list may be refilled from here on
         };
+        // the big spheres are not in the hierarchy (rt_params.h n_always): one exact slot per live ray each
+        for (uint32_t q = 0; q < nAlways; ++q) {
+            const uint64_t lm = __ballot(live);
+            if (live) exact[nExact + prefix_count(lm)] = lane << 16 | (4u * q);
+            nExact += (uint32_t)__popcll(lm);
+        }
+        if (nExact > kTreeExact - 4u * kWaveSize) drainExact();  // (more than five of them: keep a round's room)
         for (;;) {
             // feed: when fewer than a round's worth of pairs is listed, every lane with top-level candidates left adds one
             if (nWork < (uint32_t)kWaveSize) {

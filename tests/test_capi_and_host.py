@@ -135,6 +135,10 @@ def test_clustered_layout_is_a_partition_with_enclosing_bounds(built, oracle, na
         if len(ids) == 0:
             assert bounds[g, 3] >= 1e29  # padding group can never pass the filter
             continue
+        if orig.shape[0] > 128 and len(ids) == 1 and g < 8 and r[ids[0]] > 4 * np.median(r) and bounds[g, 3] >= 1e29:
+            # hierarchy scan: a leading big-sphere group stays OUT of the bounds (TraceParams::n_always: every ray tests it
+            # exactly) -- its bound must then be the never-a-candidate one, and the sphere is still listed (checked above)
+            continue
         C_ = bounds[g, :3].astype(np.float64)
         s_i = np.linalg.norm(c[ids] - C_, axis=1)
         R = (s_i + r[ids]).max()

@@ -836,10 +836,11 @@ def test_launch_and_layout_knobs_give_the_same_bits(hip, scenes_mod, monkeypatch
 
 
 @pytest.mark.parametrize("env", [{"RT_TREE_LDS": "0"}, {"RT_TREE_LDS": "0", "RT_SHADOW_GRID": "0"}, {"RT_BLOCK_THREADS": "512"},
-                                 {"RT_MATS_LDS": "0", "RT_TREE_TOP": "32"}],
+                                 {"RT_MATS_LDS": "0", "RT_TREE_TOP": "32"}, {"RT_ALWAYS_BIG": "1"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_hierarchy_scan_knobs_give_the_same_bits(hip, scenes_mod, monkeypatch, env):
-    """grid10k (2,504 groups, four levels of bounds): bounds through L2 instead of LDS, smaller workgroups, a narrower top level."""
+    """grid10k (2,504 groups, four levels of bounds): bounds through L2 instead of LDS, smaller workgroups, a narrower top level,
+    the big spheres inside the hierarchy (RT_ALWAYS_BIG=1) instead of tested for every ray."""
     sc = scenes_mod.build_scene("grid10k", 1, 96, 96)
     hip.upload(sc)
     sa = hip.render(96, 96, 1, 3, 50, 1)
