@@ -184,6 +184,7 @@ RT_DEV void scan_list_deferred(const float4* __restrict__ tab, const uint32_t* _
 // fall back to resolving every group (rare; still exact).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr uint32_t kTreeWork = 768, kTreeExact = 576, kTreeReserve = 3 * kMaxLevels;  // hierarchy scan: (ray, node) and (ray, sphere) lists
+constexpr uint32_t kFarDrain = 128;                                     // hierarchy scan: exact entries that trigger a drain (far limits, below)
 constexpr uint32_t kPoolA = 640;                                        // pooled resolve: (ray, group) items per pass
 constexpr uint32_t kPoolB = 512;                                        // pooled resolve: (ray, sphere) items before a drain
 constexpr uint32_t kWaveListBytes = kPoolA * 2 + kPoolB * 2 + 64 * 8;      // item pools + per-ray best keys = 2816 B per wave
@@ -289,6 +290,26 @@ RT_DEV int bound_rejected(const float4 B, V3 g, V3 d, float a, float dO, float c
     const float b = __builtin_fmaf(-d.z, B.z, __builtin_fmaf(-d.y, B.y, __builtin_fmaf(-d.x, B.x, dO)));
     const float t = __builtin_fmaf(g.z, B.z, __builtin_fmaf(g.y, B.y, __builtin_fmaf(g.x, B.x, __builtin_fmaf(a, B.w, cr))));
     return __float_as_int(__builtin_fmaf(min_with_positive(b, bt), b, -t));  // as mfma_post: rejected <=> t > b min(b, bt)
+}
+
+// ... and the same with a FAR LIMIT (hierarchy descent): u = a * tmax * (1 + 2^-10), tmax = the ray's closest hit so far (+inf:
+// none).  The bound is also rejected when it lies wholly beyond tmax: the ray is still approaching its centre at tmax
+// (b + u < -bt: by more than the rounding of b and u) and the point at tmax is outside the inflated bound (f(tmax) > 0, with
+// f(t) a = t~ + a t (2b + a t): the filter's own margin-carrying t~, so "outside" holds for the bound inflated by M).  f falls
+// on [0, tmax] and is positive at its end, so no point of the segment is in the inflated bound -- and the hit point of every
+// root the reference accepts for a member sphere is (that is what makes the ordinary test conservative: |f_i(t^)| <= E''/a,
+// DESIGN.md 5.1).  Such roots are > tmax (1 + 2^-10) > tmax: they can neither win nor tie.  Rounding: u and b + u are
+// accurate to 3 eps (|b| + u) <= 6 eps sqrt(a) (|o| + |o'|), o' the hit point at tmax, far below bt unless o' is thousands of
+// scene sizes away -- and then b + u < 0 with the point outside means the LINE misses the bound, which the ordinary test
+// rejects anyway; the three extra roundings of f(tmax) a are <= 8 eps a G (a tmax^2 <= 2|o|^2 + 2|o'|^2 and a bound that
+// o' is close to has |C| ~ |o'|), inside every K.  tests/test_filter_margin_cpu.py emulates it against f64 roots.
+RT_DEV int bound_rejected_far(const float4 B, V3 g, V3 d, float a, float dO, float cr, float bt, float u) {
+    const float b = __builtin_fmaf(-d.z, B.z, __builtin_fmaf(-d.y, B.y, __builtin_fmaf(-d.x, B.x, dO)));
+    const float t = __builtin_fmaf(g.z, B.z, __builtin_fmaf(g.y, B.y, __builtin_fmaf(g.x, B.x, __builtin_fmaf(a, B.w, cr))));
+    const float dec = __builtin_fmaf(min_with_positive(b, bt), b, -t);
+    const float bu = b + u;
+    const float fo = __builtin_fmaf(u, b + bu, t);
+    return (bu < -bt && fo > 0.f) ? -1 : __float_as_int(dec);
 }
 
 // Cross-lane hand-off through LDS inside ONE wave (work lists, closest-hit keys, the prepared-path cache): one set of
@@ -620,7 +641,11 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
             if (live) exact[nExact + prefix_count(lm)] = lane << 16 | (4u * q);
             nExact += (uint32_t)__popcll(lm);
         }
+#ifndef RT_NO_FAR_LIMIT
+        if (nExact != 0u) drainExact();  // their hits are the far limits of the descent from its first round on
+#else
         if (nExact > kTreeExact - 4u * kWaveSize) drainExact();  // (more than five of them: keep a round's room)
+#endif
         for (;;) {
             // feed: when fewer than a round's worth of pairs is listed, every lane with top-level candidates left adds one
             if (nWork < (uint32_t)kWaveSize) {
@@ -660,12 +685,24 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
             }
             const float fcr = faoo * (internal ? (1.f - 2.f * kMarginKValu * 5.9604645e-8f) : (1.f - 2.f * kMarginKLeaf * 5.9604645e-8f));
             uint32_t rb = 0u;
+#ifndef RT_NO_FAR_LIMIT
+            // far limit: the ray's closest hit so far (high word of its key in LDS; a stale value is larger, hence still valid)
+            const uint32_t tbits = reinterpret_cast<const uint32_t*>(best + r)[1];
+            const float fu = tbits < 0x7f800000u ? (fa * __uint_as_float(tbits)) * (1.f + 0x1p-10f) : __builtin_inff();
+            rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected_far(B0, fg, fd, fa, fdO, fcr, fbt, fu), 31);
+            rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected_far(B1, fg, fd, fa, fdO, fcr, fbt, fu), 31);
+            rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected_far(B2, fg, fd, fa, fdO, fcr, fbt, fu), 31);
+            rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected_far(B3, fg, fd, fa, fdO, fcr, fbt, fu), 31);
+            const uint32_t m = has ? (~rb & 15u) : 0u;  // bit 3-q = child 4j + q
+            if (nExact >= kFarDrain) drainExact();  // early and often: every exact round may pull the far limits in
+#else
             rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B0, fg, fd, fa, fdO, fcr, fbt), 31);
             rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B1, fg, fd, fa, fdO, fcr, fbt), 31);
             rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B2, fg, fd, fa, fdO, fcr, fbt), 31);
             rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(B3, fg, fd, fa, fdO, fcr, fbt), 31);
             const uint32_t m = has ? (~rb & 15u) : 0u;  // bit 3-q = child 4j + q
             if (nExact > kTreeExact - 4u * kWaveSize) drainExact();
+#endif
             {   // one prefix sum per list over the lanes' survivor counts (a lane's survivors all go to the same list), then
                 // every lane appends its own 0..4 entries -- instead of eight ballots and conditional stores per round
                 const uint32_t nh = (uint32_t)__builtin_popcount(m);

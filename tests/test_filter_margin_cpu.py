@@ -95,3 +95,100 @@ def test_split_bf16_filter_never_rejects_a_real_candidate(built, oracle, seed, s
             disc = ((b * b).astype(F) - (a * cc).astype(F)).astype(F)
             missed += int(np.count_nonzero((disc > 0) & ~passes))
     assert missed == 0
+
+
+def _fma(a, b, c):
+    """f32 fma: exact product and sum in f64 (53 bits hold a 24 x 24 bit product), one rounding"""
+    return (np.asarray(a, dtype=np.float64) * np.asarray(b, dtype=np.float64) + np.asarray(c, dtype=np.float64)).astype(F)
+
+
+def _reference_root(o, d, a, cx, cy, cz, r):
+    """Sphere::Intersect in the reference's operation order (ray-tracing.cpp:44-71): accepted?, t"""
+    ocx, ocy, ocz = (o[:, 0] - F(cx)).astype(F), (o[:, 1] - F(cy)).astype(F), (o[:, 2] - F(cz)).astype(F)
+    b = (((ocx * d[:, 0]).astype(F) + (ocy * d[:, 1]).astype(F)).astype(F) + (ocz * d[:, 2]).astype(F)).astype(F)
+    cc = ((((ocx * ocx).astype(F) + (ocy * ocy).astype(F)).astype(F) + (ocz * ocz).astype(F)).astype(F) - F(r) * F(r)).astype(F)
+    disc = ((b * b).astype(F) - (a * cc).astype(F)).astype(F)
+    with np.errstate(invalid="ignore"):
+        sq = np.sqrt(disc).astype(F)
+        t = ((-b - sq).astype(F) / a).astype(F)
+        t2 = ((-b + sq).astype(F) / a).astype(F)
+    t = np.where(t > F(0.001), t, t2)
+    return (disc > 0) & (t > F(0.001)), t
+
+
+@pytest.mark.parametrize("seed,scale,offset", [(11, 1.0, 0.0), (12, 1.0, 3000.0), (13, 0.01, 5.0), (14, 100.0, 2.0e4), (15, 1.0, 0.0)])
+def test_far_limit_of_the_descent_never_rejects_a_nearer_or_equal_root(built, oracle, seed, scale, offset):
+    """rt_scan.h bound_rejected_far (hierarchy descent): a bound is dropped when it lies wholly beyond the ray's closest hit
+    so far.  Emulated in f32 against the reference-order roots of the member spheres: whenever the far test fires for tmax,
+    every root the reference would accept inside that bound is > tmax -- for group bounds (K = 2048, from the host's layout)
+    and for one-sphere bounds (K = 64, rebuilt here by the host's formula), with tmax taken from real hits of other spheres
+    along the same ray, scaled by 1/2, 1 and 2."""
+    rng = np.random.default_rng(seed)
+    n = 1600  # > 128 groups: the hierarchy scan's VALU levels (K = 2048)
+    sph = np.zeros(n, dtype=oracle.SPHERE_DTYPE)
+    c = rng.uniform(-20, 20, (n, 3))
+    c[:, 1] = np.abs(c[:, 1]) * 0.1
+    sph["cx"], sph["cy"], sph["cz"] = ((c * scale + offset).astype(F)).T
+    sph["r"] = (np.exp(rng.uniform(np.log(0.05), np.log(0.6), n)) * scale).astype(F)
+    orig, bounds = layout(built, sph)
+    assert orig.shape[0] > 128
+    m = 1200
+    o = (rng.uniform(-25, 25, (m, 3)) * rng.choice([1.0, 1.0, 4.0], (m, 1)) * scale + offset).astype(F)
+    o[:, 1] = (np.abs(o[:, 1] - F(offset)) * F(0.3) + F(offset)).astype(F)
+    tgt = (rng.uniform(-20, 20, (m, 3)) * [1, 0.05, 1] * scale + offset)
+    d = np.where(rng.random((m, 1)) < 0.8, tgt - o, rng.normal(size=(m, 3)))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True) * rng.choice([1.0, 1.0, 0.3, 7.0], (m, 1))).astype(F)  # not all unit length
+    a = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(F) + d[:, 2] * d[:, 2]).astype(F)
+    dO = ((d[:, 0] * o[:, 0] + d[:, 1] * o[:, 1]).astype(F) + d[:, 2] * o[:, 2]).astype(F)
+    oo = ((o[:, 0] * o[:, 0] + o[:, 1] * o[:, 1]).astype(F) + o[:, 2] * o[:, 2]).astype(F)
+    g = ((F(-2.0) * a).astype(F)[:, None] * o).astype(F)
+    Cn = np.linalg.norm(bounds[:, :3].astype(np.float64), axis=1)
+    Rf = np.sqrt(np.maximum(0.0, Cn * Cn - bounds[:, 3].astype(np.float64)))
+    real = bounds[:, 3] < 1e29
+    bound_norm = F((Cn[real] + Rf[real]).max() * 1.001)
+    bt = (F(1e-4) * np.sqrt(a).astype(F) * (np.sqrt(oo).astype(F) + bound_norm)).astype(F)
+    # closest hits along every ray: the far limits a descent would really see (every sphere, reference order)
+    hits = np.full((m, 3), np.inf, dtype=F)
+    roots = {}
+    for i in range(n):
+        ok, t = _reference_root(o, d, a, sph["cx"][i], sph["cy"][i], sph["cz"][i], sph["r"][i])
+        roots[i] = (ok, t)
+        tt = np.where(ok, t, np.inf).astype(F)
+        hits[:, 0] = np.minimum(hits[:, 0], tt)                       # the closest hit
+        hits[:, 1] = np.where(rng.random(m) < 0.03, np.minimum(hits[:, 1], tt), hits[:, 1])  # some hit or other
+    hits[:, 2] = hits[:, 0]
+    tmaxes = [hits[:, 0], hits[:, 1], (hits[:, 1] * F(0.5)).astype(F), (hits[:, 2] * F(2.0)).astype(F)]
+
+    def far_rejects(B, K, tmax):
+        cr = ((a * oo).astype(F) * F(1.0 - 2.0 * K * EPS)).astype(F)
+        b = _fma(-d[:, 2], B[2], _fma(-d[:, 1], B[1], _fma(-d[:, 0], B[0], dO)))
+        t = _fma(g[:, 2], B[2], _fma(g[:, 1], B[1], _fma(g[:, 0], B[0], _fma(a, B[3], cr))))
+        u = ((a * tmax).astype(F) * F(1.0 + 2.0 ** -10)).astype(F)
+        bu = (b + u).astype(F)
+        with np.errstate(invalid="ignore", over="ignore"):
+            fo = _fma(u, (b + bu).astype(F), t)
+        return np.isfinite(tmax) & (bu < -bt) & (fo > 0)
+
+    wrong = fired = 0
+    for gi in range(orig.shape[0]):
+        ids = orig[gi][orig[gi] != 0xFFFFFFFF]
+        if len(ids) == 0 or not real[gi]:
+            continue
+        for tmax in tmaxes:
+            rej = far_rejects(bounds[gi], 2048.0, tmax)
+            fired += int(rej.sum())
+            for i in ids:
+                ok, t = roots[i]
+                wrong += int(np.count_nonzero(rej & ok & ~(t > tmax)))
+        for i in ids:  # the member's one-sphere bound (host: BoundOf of a single sphere, K = 64)
+            cx, cy, cz, r = (float(sph[k][i]) for k in ("cx", "cy", "cz", "r"))
+            C2 = cx * cx + cy * cy + cz * cz
+            Rf2 = r * r * (1.0 + 1e-5) + 64.0 * EPS * (2.0 * (np.sqrt(C2) + r) ** 2 + r * r)
+            w = np.nextafter(np.nextafter(F(C2 - Rf2), F(-np.inf)), F(-np.inf))
+            ok, t = roots[i]
+            for tmax in tmaxes:
+                rej = far_rejects((F(cx), F(cy), F(cz), w), 64.0, tmax)
+                fired += int(rej.sum())
+                wrong += int(np.count_nonzero(rej & ok & ~(t > tmax)))
+    assert fired > 10000  # the test does exercise the far limit
+    assert wrong == 0
