@@ -160,6 +160,8 @@ struct SceneLayout {
     float boundNorm = 0.f;        // max |C| + R
     unsigned long long singleMask[2] = {0ull, 0ull};  // groups of one sphere, in the flat scan's bitmap coordinates
     uint32_t nAlways = 0;         // hierarchy scan: leading big-sphere groups kept out of the hierarchy (tested for every ray)
+    float treeBox[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // box around the spheres in the hierarchy (lo, hi, max |coordinate|)
+    bool treeBoxOn = false;
 };
 
 // Conservative bounding sphere of a set of spheres, in the filter's (C, |C|^2 - Rf^2) form.
@@ -414,6 +416,33 @@ static void BuildLayout(const rt_sphere* sp, uint32_t n, uint32_t topMax, SceneL
         for (size_t j = 0; j < up.size(); ++j)
             for (int q = 0; q < 4; ++q) up[j].insert(up[j].end(), cur[4 * j + q].begin(), cur[4 * j + q].end());
         levels.push_back(std::move(up));
+    }
+    L.treeBoxOn = false;
+    if (levels.size() > 1 && std::getenv("RT_TREE_BOX_OFF") == nullptr) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        double A = 0.0, rmin = 1e300;
+        for (const auto& ids : levels[0])
+            for (uint32_t k : ids) {
+                const double c[3] = {sp[k].cx, sp[k].cy, sp[k].cz};
+                A = std::max(A, std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + (double)sp[k].r);
+                rmin = std::min(rmin, (double)sp[k].r);
+                for (int a = 0; a < 3; ++a) {
+                    lo[a] = std::min(lo[a], c[a] - (double)sp[k].r * (1.0 + 1e-5));
+                    hi[a] = std::max(hi[a], c[a] + (double)sp[k].r * (1.0 + 1e-5));
+                }
+            }
+        if (lo[0] <= hi[0]) {
+            double am = 0;
+            for (int a = 0; a < 3; ++a) {
+                L.treeBox[a] = std::nextafterf((float)lo[a], -INFINITY);
+                L.treeBox[3 + a] = std::nextafterf((float)hi[a], INFINITY);
+                am = std::max(am, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
+            }
+            L.treeBox[6] = (float)(am * 1.001);
+            L.treeBox[7] = (float)(3.0 * A * A * 1.001);
+            L.treeBox[8] = (float)(1.001 / (2.0 * rmin));
+            L.treeBoxOn = true;
+        }
     }
     L.tree.clear();
     L.nLevels = (uint32_t)levels.size();
@@ -1101,6 +1130,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     }
     b.bound_norm = L.boundNorm;
     b.n_always = L.nAlways;
+    for (int k = 0; k < 9; ++k) b.tree_box[k] = L.treeBox[k];
+    b.tree_box_on = L.treeBoxOn ? 1u : 0u;
     b.single_mask[0] = std::getenv("RT_SINGLE_DIRECT") && std::atoi(std::getenv("RT_SINGLE_DIRECT")) == 0 ? 0ull : L.singleMask[0];
     b.single_mask[1] = std::getenv("RT_SINGLE_DIRECT") && std::atoi(std::getenv("RT_SINGLE_DIRECT")) == 0 ? 0ull : L.singleMask[1];
     b.radius = ctx->radius.ptr;

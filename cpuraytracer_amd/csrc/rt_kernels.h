@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         if (kMfma) {
             // every lane takes part: lane l also supplies operands for, and filters half the spheres of,
             // the ray owned by lane l^32, whether or not its own ray is live
-            scan_list_mfma<kScan == 2>(scanTab, leafTab, origTab, mfmaOps, nTiles, nTop, treeTab, p.level_off, p.n_levels, p.bound_norm, p.single_mask, p.n_always, ro, rd,
+            scan_list_mfma<kScan == 2>(scanTab, leafTab, origTab, mfmaOps, nTiles, nTop, treeTab, p.level_off, p.n_levels, p.bound_norm, p.single_mask, p.n_always, p.tree_box_on ? p.tree_box : nullptr, ro, rd,
                                        state != kIdle, tmin, idx, waveCand, lane, dbgScan);
         } else if (state != kIdle) {
             scan_list_deferred(scanTab, origTab, p.n_padded, ro, rd, tmin, idx, cand);
@@ -976,7 +976,7 @@ __global__ void __launch_bounds__(256) k_unit_closest(const TraceParams p, const
     unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)dbg;
     if (kScan != 0) {
-        scan_list_mfma<kScan == 2>(T.scan, T.leaf, T.orig, T.ops, T.nTiles, T.nTop, T.tree, p.level_off, p.n_levels, p.bound_norm, p.single_mask, p.n_always, o, d, live,
+        scan_list_mfma<kScan == 2>(T.scan, T.leaf, T.orig, T.ops, T.nTiles, T.nTop, T.tree, p.level_off, p.n_levels, p.bound_norm, p.single_mask, p.n_always, p.tree_box_on ? p.tree_box : nullptr, o, d, live,
                                    tmin, idx, waveCand, lane, dbg);
     } else if (live) {
         scan_list_deferred(T.scan, T.orig, p.n_padded, o, d, tmin, idx, waveCand + lane);

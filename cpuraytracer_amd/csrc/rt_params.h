@@ -124,6 +124,9 @@ struct TraceParams {
     uint32_t mats_in_lds;      // stage the material table into LDS (else it is read through L2)
     float bound_norm;          // max over groups of |C| + R (scale of the filter's behind-the-origin threshold)
     unsigned long long single_mask[2];  // flat scan: groups of ONE sphere, as bits of the two candidate-bitmap halves (rt_scan.h)
+    float tree_box[9];         // hierarchy scan: lo.xyz, hi.xyz of the box around every sphere IN the hierarchy (radii included), max |coordinate|,
+                               // [7] = 3 A^2 (A = max |c| + r of those spheres), [8] = 1 / (2 r_min): the per-ray padding's constants (rt_scan.h)
+    uint32_t tree_box_on;      // ... valid: rays are clipped to it (near and far limits of the descent, rt_scan.h)
     uint32_t n_always;         // hierarchy scan: the first n_always groups hold one big sphere each and are NOT in the hierarchy:
                                // every live ray tests them exactly (a floor inside the bounds makes every node above it a candidate)
     uint32_t n_padded;         // 4 * n_groups + 4

@@ -312,6 +312,19 @@ RT_DEV int bound_rejected_far(const float4 B, V3 g, V3 d, float a, float dO, flo
     return (bu < -bt && fo > 0.f) ? -1 : __float_as_int(dec);
 }
 
+// ... and with a NEAR limit as well (un = a * tnear * (1 - 2^-10), or -inf): the bound lies wholly before tnear when the ray has
+// passed its centre there (b + un > bt) and the point at tnear is outside the inflated bound.
+RT_DEV int bound_rejected_span(const float4 B, V3 g, V3 d, float a, float dO, float cr, float bt, float un, float uf) {
+    const float b = __builtin_fmaf(-d.z, B.z, __builtin_fmaf(-d.y, B.y, __builtin_fmaf(-d.x, B.x, dO)));
+    const float t = __builtin_fmaf(g.z, B.z, __builtin_fmaf(g.y, B.y, __builtin_fmaf(g.x, B.x, __builtin_fmaf(a, B.w, cr))));
+    const float dec = __builtin_fmaf(min_with_positive(b, bt), b, -t);
+    const float bf = b + uf;
+    const float ff = __builtin_fmaf(uf, b + bf, t);
+    const float bn = b + un;
+    const float fn = __builtin_fmaf(un, b + bn, t);
+    return ((bf < -bt && ff > 0.f) || (bn > bt && fn > 0.f)) ? -1 : __float_as_int(dec);
+}
+
 // Cross-lane hand-off through LDS inside ONE wave (work lists, closest-hit keys, the prepared-path cache): one set of
 // lanes stores, other lanes of the same wave load right after.  The hardware executes a wave's LDS operations in order;
 // this stops the COMPILER from moving may-alias accesses across the hand-off (it emits no instruction beyond, at most, a
@@ -358,7 +371,7 @@ template <bool kTree>
 RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restrict__ leaf, const uint32_t* __restrict__ orig,
                            const float* __restrict__ ops, uint32_t nTiles,
                            uint32_t nTop, const float4* __restrict__ tree, const uint32_t* levelOff, uint32_t nLevels, float boundNorm,
-                           const unsigned long long* singleMask, uint32_t nAlways, V3 o, V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand, uint32_t lane, unsigned long long* dbg) {
+                           const unsigned long long* singleMask, uint32_t nAlways, const float* treeBox, V3 o, V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand, uint32_t lane, unsigned long long* dbg) {
     const float a = dot3(d, d);
     tmin = __builtin_inff();
     idx = -1;
@@ -607,6 +620,37 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
         const uint32_t topLevel = nLevels - 1u;
         const float aoo = a * oo;
         uint32_t nWork = 0, nExact = 0;
+        // The ray clipped to the box around every sphere in the hierarchy: roots can only lie in [tn, tf] (widened by 2^-10 and
+        // by 16 eps of the coordinates' magnitude in position), so the descent gets a near limit and a second far limit -- a flat
+        // layer of spheres (the cover scene's kind) is entered late and left early by most rays -- and a ray that misses the box
+        // has no candidates at all.  minNum/maxNum ignore the NaN of 0 * inf (an axis the ray is parallel to and inside of).
+        float boxUn = -__builtin_inff(), boxUf = __builtin_inff();
+        if (treeBox) {
+            float tn = 0.f, tf = __builtin_inff();
+            const float oc[3] = {o.x, o.y, o.z}, dc[3] = {d.x, d.y, d.z};
+            // how far outside its sphere the hit point of an ACCEPTED root can lie: the reference's discriminant is off by at most
+            // E <= 16 eps a G, G = 2|o|^2 + 2(|c| + r)^2 + r^2 <= 2|o|^2 + 3 A^2, so the point is within delta of the surface with
+            // (r + delta)^2 <= r^2 + E''/a: delta <= min(sqrt(X), X / (2 r_min)), X = 32 eps (2|o|^2 + 3 A^2) (twice E for the root's
+            // own square root and division)
+            const float X = 32.f * 5.9604645e-8f * __builtin_fmaf(2.f, oo, treeBox[7]);
+            const float reach = __builtin_fminf(__builtin_sqrtf(X), X * treeBox[8]);
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const float pad = reach + 1e-6f * (__builtin_fabsf(oc[ax]) + treeBox[6]);
+                const float inv = __builtin_amdgcn_rcpf(dc[ax]);
+                const float t0 = ((treeBox[ax] - pad) - oc[ax]) * inv, t1 = ((treeBox[3 + ax] + pad) - oc[ax]) * inv;
+                tn = __builtin_fmaxf(tn, __builtin_fminf(t0, t1));
+                tf = __builtin_fminf(tf, __builtin_fmaxf(t0, t1));
+            }
+            tn *= 1.f - 0x1p-10f;
+            tf *= 1.f + 0x1p-10f;
+            if (tn > tf || !(tf > 0.f)) {  // the ray misses the box (or leaves it behind its origin)
+                cur = 0ull;
+                nxt = 0ull;
+            }
+            if (tn > 0.f) boxUn = a * tn;
+            boxUf = a * tf;
+        }
         auto drainExact = [&]() {
             wave_lds_handoff();  // exact-list entries written by other lanes
             for (uint32_t base = 0; base < nExact; base += kWaveSize) {
@@ -688,11 +732,20 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
 #ifndef RT_NO_FAR_LIMIT
             // far limit: the ray's closest hit so far (high word of its key in LDS; a stale value is larger, hence still valid)
             const uint32_t tbits = reinterpret_cast<const uint32_t*>(best + r)[1];
-            const float fu = tbits < 0x7f800000u ? (fa * __uint_as_float(tbits)) * (1.f + 0x1p-10f) : __builtin_inff();
+            float fu = tbits < 0x7f800000u ? (fa * __uint_as_float(tbits)) * (1.f + 0x1p-10f) : __builtin_inff();
+            if (treeBox) {
+                const float fun = lane_fetch(r, boxUn);
+                fu = __builtin_fminf(fu, lane_fetch(r, boxUf));
+                rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected_span(B0, fg, fd, fa, fdO, fcr, fbt, fun, fu), 31);
+                rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected_span(B1, fg, fd, fa, fdO, fcr, fbt, fun, fu), 31);
+                rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected_span(B2, fg, fd, fa, fdO, fcr, fbt, fun, fu), 31);
+                rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected_span(B3, fg, fd, fa, fdO, fcr, fbt, fun, fu), 31);
+            } else {
             rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected_far(B0, fg, fd, fa, fdO, fcr, fbt, fu), 31);
             rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected_far(B1, fg, fd, fa, fdO, fcr, fbt, fu), 31);
             rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected_far(B2, fg, fd, fa, fdO, fcr, fbt, fu), 31);
             rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected_far(B3, fg, fd, fa, fdO, fcr, fbt, fu), 31);
+            }
             const uint32_t m = has ? (~rb & 15u) : 0u;  // bit 3-q = child 4j + q
             if (nExact >= kFarDrain) drainExact();  // early and often: every exact round may pull the far limits in
 #else

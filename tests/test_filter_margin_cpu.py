@@ -192,3 +192,94 @@ def test_far_limit_of_the_descent_never_rejects_a_nearer_or_equal_root(built, or
                 wrong += int(np.count_nonzero(rej & ok & ~(t > tmax)))
     assert fired > 10000  # the test does exercise the far limit
     assert wrong == 0
+
+
+@pytest.mark.parametrize("seed,scale,offset", [(21, 1.0, 0.0), (22, 1.0, 3000.0), (23, 0.01, 5.0), (24, 100.0, 2.0e4), (25, 1.0, 0.0)])
+def test_box_clip_of_the_descent_keeps_every_accepted_root(built, oracle, seed, scale, offset):
+    """rt_scan.h, hierarchy descent: rays are clipped to the box around the spheres in the hierarchy, padded per ray by the reach
+    of an accepted root outside its sphere (the reference's discriminant is off by up to 16 eps a G).  Emulated in f32, with
+    rays that graze spheres exactly where they touch the box -- from 10, 300 and 3,000 scene units away, where the rounding is
+    largest: (I) no accepted reference root lies outside the widened interval, and a ray declared to miss the box has none;
+    (II) whenever the near/far test of a bound fires, no member sphere has an accepted root."""
+    rng = np.random.default_rng(seed)
+    n = 900  # > 128 groups; a flat layer like the cover scene's small spheres
+    sph = np.zeros(n, dtype=oracle.SPHERE_DTYPE)
+    c = rng.uniform(-15, 15, (n, 3))
+    c[:, 1] = 0.2 + 0.05 * rng.random(n)
+    sph["cx"], sph["cy"], sph["cz"] = ((c * scale + offset).astype(F)).T
+    sph["r"] = (np.exp(rng.uniform(np.log(0.1), np.log(0.3), n)) * scale).astype(F)
+    orig, bounds = layout(built, sph)
+    assert orig.shape[0] > 128
+    cs = np.stack([sph["cx"], sph["cy"], sph["cz"]], 1).astype(np.float64)
+    rs = sph["r"].astype(np.float64)
+    # the host's box (rt_capi.hip BuildLayout) and the padding constants
+    lo = np.array([np.nextafter(F((cs[:, k] - rs * (1 + 1e-5)).min()), F(-np.inf)) for k in range(3)], dtype=F)
+    hi = np.array([np.nextafter(F((cs[:, k] + rs * (1 + 1e-5)).max()), F(np.inf)) for k in range(3)], dtype=F)
+    absmax = F(max(np.abs(lo.astype(np.float64)).max(), np.abs(hi.astype(np.float64)).max()) * 1.001)
+    A = (np.linalg.norm(cs, axis=1) + rs).max()
+    A2 = F(3.0 * A * A * 1.001)
+    inv2r = F(1.001 / (2.0 * rs.min()))
+    # rays: random ones, and grazers of the sphere tops / sides from far away
+    m0 = 600
+    o = (rng.uniform(-20, 20, (m0, 3)) * [1, 0.2, 1] * scale + offset).astype(np.float64)
+    tgt = (rng.uniform(-15, 15, (m0, 3)) * [1, 0.02, 1] * scale + offset)
+    d = tgt - o
+    graz_o, graz_d = [], []
+    for i in rng.integers(0, n, 300):
+        for L in (10.0, 300.0, 3000.0):
+            ax = int(rng.integers(0, 3)); sgn = rng.choice([-1.0, 1.0])
+            pnt = cs[i].copy(); pnt[ax] += sgn * rs[i] * (1.0 + rng.choice([-1e-4, -1e-6, 0.0, 1e-6, 1e-4]))
+            dirv = rng.normal(size=3); dirv[ax] = rng.normal() * 1e-4; dirv /= np.linalg.norm(dirv)
+            graz_o.append(pnt - L * scale * dirv); graz_d.append(dirv * rng.choice([1.0, 0.3, 5.0]))
+    o = np.concatenate([o, np.array(graz_o)]).astype(F)
+    d = np.concatenate([d / np.linalg.norm(d, axis=1, keepdims=True), np.array(graz_d)]).astype(F)
+    m = o.shape[0]
+    a = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(F) + d[:, 2] * d[:, 2]).astype(F)
+    dO = ((d[:, 0] * o[:, 0] + d[:, 1] * o[:, 1]).astype(F) + d[:, 2] * o[:, 2]).astype(F)
+    oo = ((o[:, 0] * o[:, 0] + o[:, 1] * o[:, 1]).astype(F) + o[:, 2] * o[:, 2]).astype(F)
+    g = ((F(-2.0) * a).astype(F)[:, None] * o).astype(F)
+    # device: the clip
+    X = (F(32.0) * F(EPS) * _fma(F(2.0), oo, A2)).astype(F)
+    reach = np.minimum(np.sqrt(X).astype(F), (X * inv2r).astype(F))
+    tn = np.zeros(m, dtype=F); tf = np.full(m, np.inf, dtype=F)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        for ax in range(3):
+            pad = (reach + (F(1e-6) * (np.abs(o[:, ax]) + absmax).astype(F)).astype(F)).astype(F)
+            inv = (F(1.0) / d[:, ax]).astype(F)
+            t0 = ((((lo[ax] - pad).astype(F) - o[:, ax]).astype(F)) * inv).astype(F)
+            t1 = ((((hi[ax] + pad).astype(F) - o[:, ax]).astype(F)) * inv).astype(F)
+            tn = np.fmax(tn, np.fmin(t0, t1)); tf = np.fmin(tf, np.fmax(t0, t1))
+    tn = (tn * F(1.0 - 2.0 ** -10)).astype(F); tf = (tf * F(1.0 + 2.0 ** -10)).astype(F)
+    empty = (tn > tf) | ~(tf > 0)
+    un = np.where(tn > 0, (a * tn).astype(F), F(-np.inf)).astype(F)
+    uf = (a * tf).astype(F)
+    roots = {}
+    outside = 0
+    hits = 0
+    for i in range(n):
+        ok, t = _reference_root(o, d, a, sph["cx"][i], sph["cy"][i], sph["cz"][i], sph["r"][i])
+        roots[i] = (ok, t)
+        hits += int(ok.sum())
+        outside += int(np.count_nonzero(ok & (empty | (t < tn) | (t > tf))))
+    assert hits > 3000 and outside == 0  # (I)
+    Cn = np.linalg.norm(bounds[:, :3].astype(np.float64), axis=1)
+    Rf = np.sqrt(np.maximum(0.0, Cn * Cn - bounds[:, 3].astype(np.float64)))
+    real = bounds[:, 3] < 1e29
+    bt = (F(1e-4) * np.sqrt(a).astype(F) * (np.sqrt(oo).astype(F) + F((Cn[real] + Rf[real]).max() * 1.001))).astype(F)
+    cr = ((a * oo).astype(F) * F(1.0 - 2.0 * 2048.0 * EPS)).astype(F)
+    wrong = fired = 0
+    with np.errstate(invalid="ignore", over="ignore"):
+        for gi in range(orig.shape[0]):
+            ids = orig[gi][orig[gi] != 0xFFFFFFFF]
+            if len(ids) == 0 or not real[gi]:
+                continue
+            B = bounds[gi]
+            b = _fma(-d[:, 2], B[2], _fma(-d[:, 1], B[1], _fma(-d[:, 0], B[0], dO)))
+            t = _fma(g[:, 2], B[2], _fma(g[:, 1], B[1], _fma(g[:, 0], B[0], _fma(a, B[3], cr))))
+            bf = (b + uf).astype(F); ff = _fma(uf, (b + bf).astype(F), t)
+            bn = (b + un).astype(F); fn = _fma(un, (b + bn).astype(F), t)
+            rej = ~empty & (((bf < -bt) & (ff > 0)) | ((bn > bt) & (fn > 0)))
+            fired += int(rej.sum())
+            for i in ids:
+                wrong += int(np.count_nonzero(rej & roots[i][0]))
+    assert wrong == 0 and (fired > 10000 or offset != 0.0)  # (II); far from the origin the padding swallows the layer: nothing to fire
