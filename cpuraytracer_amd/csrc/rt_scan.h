@@ -692,9 +692,20 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
 #endif
         for (;;) {
             // feed: when fewer than a round's worth of pairs is listed, every lane with top-level candidates left adds one
-            if (nWork < (uint32_t)kWaveSize) {
+            // (until the round is full or nobody has a candidate left: a fed candidate may be dropped, below)
+            while (nWork < (uint32_t)kWaveSize && __ballot((cur | nxt) != 0ull) != 0ull) {
                 uint32_t t = 0;
-                const bool add = next_candidate(cur, nxt, hOff, t);
+                bool add = next_candidate(cur, nxt, hOff, t);
+                if (add) {
+                    // the lane owns this ray: the candidate node ITSELF against the ray's span (closest hit so far, box entry and
+                    // exit), before anybody visits it -- one bound test instead of a round's slot and four child tests
+                    const uint32_t tb = reinterpret_cast<const uint32_t*>(best + lane)[1];
+                    float fu = tb < 0x7f800000u ? (a * __uint_as_float(tb)) * (1.f + 0x1p-10f) : __builtin_inff();
+                    fu = __builtin_fminf(fu, boxUf);
+                    const float4 Bn = tree[levelOff[topLevel] + t];
+                    const float crTop = aoo * (1.f - 2.f * kMarginK * 5.9604645e-8f);  // the top level's bounds carry the matrix-core K
+                    add = bound_rejected_span(Bn, v3(gx, gy, gz), d, a, dO, crTop, bt, boxUn, fu) >= 0;
+                }
                 const uint64_t am = __ballot(add);
                 if (add) work[nWork + prefix_count(am)] = lane << 20 | topLevel << 16 | t;
                 nWork += (uint32_t)__popcll(am);
