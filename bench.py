@@ -238,7 +238,7 @@ def main():
         if os.environ.get("RT_BENCH_DUMP_LDR"):  # tests: the gathered image of the last step
             import numpy as np
             np.save(os.environ["RT_BENCH_DUMP_LDR"], full)
-        kernel_name = ("rt_trace_kernel<bounds hierarchy, 1024 threads, matrix-core top level + pooled descent>" if args.config == "c5"
+        kernel_name = ("rt_trace_kernel<bounds hierarchy, 1024 threads, matrix-core top level + pooled descent, path cache>" if args.config == "c5"
                        else "rt_trace_kernel<LDS tables, 1024 threads, matrix-core filter, path cache>")
         roofline, cull = roofline_object(cfg, kernel_name, avg_ms, avg_trav, n_spheres, kernel_sources_hash())
         out = {

@@ -183,11 +183,20 @@ RT_DEV void scan_list_deferred(const float4* __restrict__ tab, const uint32_t* _
 // with its own sub-list and register counter (no atomics).  A sub-list that overflows makes its ray
 // fall back to resolving every group (rare; still exact).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr uint32_t kTreeWork = 768, kTreeExact = 576, kTreeReserve = 3 * kMaxLevels;  // hierarchy scan: (ray, node) and (ray, sphere) lists
+// (round 1: 768 + 576 entries.  Since the descent culls by span the lists run short: 384 + 384 measures the same, and 320 + 384
+// leaves grid10k's LDS image room for the prepared-path cache, +3 %; 256 + 384 loses 6 %.)
+#ifndef RT_TREE_WORK
+#define RT_TREE_WORK 320
+#endif
+#ifndef RT_TREE_EXACT
+#define RT_TREE_EXACT 384
+#endif
+constexpr uint32_t kTreeWork = RT_TREE_WORK, kTreeExact = RT_TREE_EXACT, kTreeReserve = 3 * kMaxLevels;  // hierarchy scan: (ray, node) and (ray, sphere) lists
 constexpr uint32_t kFarDrain = 128;                                     // hierarchy scan: exact entries that trigger a drain (far limits, below)
 constexpr uint32_t kPoolA = 640;                                        // pooled resolve: (ray, group) items per pass
 constexpr uint32_t kPoolB = 512;                                        // pooled resolve: (ray, sphere) items before a drain
 constexpr uint32_t kWaveListBytes = kPoolA * 2 + kPoolB * 2 + 64 * 8;      // item pools + per-ray best keys = 2816 B per wave
+static_assert(kTreeExact >= kFarDrain + 4 * 64, "a round may add 256 entries to an exact list that holds up to kFarDrain - 1");
 constexpr uint32_t kWaveCandBytes = kTreeWork * 4 + kTreeExact * 4 + 64 * 8;  // hierarchy scan: 5888 B per wave
 // K of the filter margins (units of eps * a * G; the host folds the same K into each bound): the matrix-core level needs
 // 101*16 (exact-path rounding, amplified by the member offsets) + ~600 (split-bf16 operands); levels tested on the VALU
@@ -681,6 +690,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
         };
         // the big spheres are not in the hierarchy (rt_params.h n_always): one exact slot per live ray each
         for (uint32_t q = 0; q < nAlways; ++q) {
+            if (nExact + (uint32_t)kWaveSize > kTreeExact) drainExact();
             const uint64_t lm = __ballot(live);
             if (live) exact[nExact + prefix_count(lm)] = lane << 16 | (4u * q);
             nExact += (uint32_t)__popcll(lm);
