@@ -52,6 +52,7 @@ CONFIGS = {
                metric="Msamples/sec (WxHxspp/s), 4096x4096 grid10k scene (10,004 spheres) spp=64 d=50", pmc="r02_pmc_summary_c5.json"),
 }
 PEAK_VALU_TLANEOPS = 78.6   # 256 CU x 4 SIMD x 64 lanes / 2 cycles per wave-instruction x 2.4 GHz (MI355X_MICROARCH.md: SIMD-32, 2 cycles)
+PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FLOPS_PER_SPHERE_TEST = 18  # Sphere::Intersect up to the discriminant: 9 mul + 9 add/sub
 
 
@@ -96,11 +97,18 @@ def cpu_baseline(cfg, target_seconds=15.0):
                       % (cfg["scene"], W, H, DEPTH, spp, cfg["spp"], cores, t1)}
 
 
-def roofline_object(cfg, kernel_name, avg_ms, avg_trav, n_spheres, src_hash):
-    """Executed-work roofline of the trace kernel (module docstring)."""
+def roofline_object(cfg, kernel_name, avg_ms, avg_trav, n_spheres, src_hash, n_gpus=1):
+    """Executed-work roofline of the trace kernel (module docstring).  The committed counters belong to ONE workload — this
+    config on one GPU: at --gpus N > 1 rank 0 renders every N-th row at N x the samples per pixel, another instruction
+    count, so the fraction is withheld there (frac = null + reason) instead of pricing a different launch with them."""
     rl = {"bound": "valu-issue", "kernel": kernel_name, "achieved": None, "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",
           "frac": None, "traffic": None, "launch_ms": avg_ms, "pmc_source": "profiles/" + cfg["pmc"],
           "kernel_sources_sha256": src_hash}
+    if n_gpus != 1:
+        rl["pmc_source"] = None
+        rl["error"] = ("withheld at n_gpus=%d: the committed PMC counters (profiles/%s) are those of the 1-GPU launch; rank 0's strip "
+                       "(every %d-th row at %dx the spp) executes a different instruction count" % (n_gpus, cfg["pmc"], n_gpus, n_gpus))
+        return rl, None
     path = os.path.join(ROOT, "profiles", cfg["pmc"])
     try:
         d = json.load(open(path))
@@ -110,6 +118,11 @@ def roofline_object(cfg, kernel_name, avg_ms, avg_trav, n_spheres, src_hash):
     if d.get("kernel_sources_sha256") != src_hash:
         rl["error"] = ("PMC summary %s was taken from kernel sources %s..., this library is %s...: re-run tools/profile_round.sh"
                        % (cfg["pmc"], str(d.get("kernel_sources_sha256"))[:12], src_hash[:12]))
+        print("bench.py: WARNING: " + rl["error"], file=sys.stderr, flush=True)
+        return rl, None
+    wl = d.get("workload_key")  # summaries written since round 3 record what was profiled (n_gpus, W, H, spp)
+    if wl is not None and (wl.get("n_gpus", 1), wl.get("W"), wl.get("H"), wl.get("spp")) != (1, cfg["W"], cfg["H"], cfg["spp"]):
+        rl["error"] = "PMC summary %s was taken on workload %s, not on %dx%d spp %d on 1 GPU" % (cfg["pmc"], wl, cfg["W"], cfg["H"], cfg["spp"])
         print("bench.py: WARNING: " + rl["error"], file=sys.stderr, flush=True)
         return rl, None
     t = d["raw_counters"]["trace"]
@@ -131,6 +144,28 @@ def roofline_object(cfg, kernel_name, avg_ms, avg_trav, n_spheres, src_hash):
     cull = FLOPS_PER_SPHERE_TEST * avg_trav * n_spheres / lane_ops
     return rl, {"value": cull, "algorithmic": "18 flop x %d spheres x %.0f list scans per launch (SURVEY.md 8d) / executed VALU lane-operations"
                                               % (n_spheres, avg_trav)}
+
+
+def hbm_read_equivalent(avg_ms, avg_trav, n_spheres, measured_traffic_bytes):
+    """BASELINE.json north_star: "fraction of the HBM-read roofline".  SURVEY.md §8(d): an exhaustive list scan reads 16 bytes per
+    sphere record, so the ALGORITHMIC read stream of a launch is 16 x N x T bytes; divided by the launch time it is the rate a
+    kernel streaming the list from HBM would have to sustain.  The list lives in LDS (and the filters skip most of it), so this
+    legitimately exceeds 1.0 x HBM peak; the MEASURED HBM rate of the same launch (PMC FETCH_SIZE + WRITE_SIZE) stands beside it."""
+    alg = 16.0 * n_spheres * avg_trav
+    sec = avg_ms * 1e-3
+    return {"label": "algorithmic sphere-record bytes an exhaustive scan would read (16 B x N x T), NOT bytes moved",
+            "bytes_per_launch": alg, "GBps": alg / sec / 1e9, "hbm_peak_GBps": PEAK_HBM_GBPS, "frac_of_hbm_peak": alg / sec / 1e9 / PEAK_HBM_GBPS,
+            "measured_hbm_GBps": (measured_traffic_bytes / sec / 1e9) if measured_traffic_bytes else None,
+            "measured_frac_of_hbm_peak": (measured_traffic_bytes / sec / 1e9 / PEAK_HBM_GBPS) if measured_traffic_bytes else None}
+
+
+def per_rank_report(rows):
+    """rows[r] = (render_ms, accumulate_ms, resolve_ms, gather_ms, step_wall_ms) averaged over the timed steps of rank r ->
+    the `per_rank` list and the id of the rank whose device work per step was longest (where an N-GPU step's time went)."""
+    per = [{"rank": r, "render_ms": v[0], "accumulate_ms": v[1], "resolve_ms": v[2], "gather_ms": v[3], "step_wall_ms": v[4]}
+           for r, v in enumerate(rows)]
+    slowest = max(range(len(rows)), key=lambda r: rows[r][0] + rows[r][1] + rows[r][2])
+    return per, slowest
 
 
 def main():
@@ -190,16 +225,33 @@ def main():
     xch = D.StripExchange(H_IMG, W_IMG, rank, N, "cuda")  # HDR + LDR strip of this rank in one buffer: one gather per step
 
     kernel_ms, trav, last = [], [], None
+    phase = {"render": 0.0, "accumulate": 0.0, "resolve": 0.0, "gather": 0.0, "wall": 0.0}
+    gather_events = []
 
-    def step():
+    def step(timed=False):
         nonlocal last
+        w0 = time.perf_counter()
         st = r.render(W_IMG, H_IMG, 1, 1 + spp, DEPTH, RENDER_SEED, rowset=rs)
-        r.resolve()
+        res_ms = r.resolve()
         r.copy_to_device(xch.hdr.data_ptr(), xch.ldr.data_ptr())
         if rehearsal:
             r.synchronize()
+        g0 = time.perf_counter()
+        if timed and N > 1 and not rehearsal:  # events on the stream the gather is enqueued on (torch's current stream here)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
         parts_h, parts_l = xch.gather(through_host=rehearsal)  # RCCL gather of the strips (no-op at N = 1)
+        if timed and N > 1 and not rehearsal:
+            e1.record(stream)
+            gather_events.append((e0, e1))
+        elif timed and N > 1:
+            phase["gather"] += (time.perf_counter() - g0) * 1e3
         last = (st, parts_h, parts_l)
+        if timed:
+            phase["render"] += st.ms_render
+            phase["accumulate"] += st.ms_accumulate
+            phase["resolve"] += float(res_ms or 0.0)
+            phase["wall"] += (time.perf_counter() - w0) * 1e3
         return st
 
     def sync():
@@ -213,7 +265,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        st = step()
+        st = step(timed=True)
         kernel_ms.append(st.ms_render)
         trav.append(st.traversals)
     sync()
@@ -222,6 +274,14 @@ def main():
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    for e0, e1 in gather_events:
+        phase["gather"] += e0.elapsed_time(e1)
+    k = float(max(1, args.steps))
+    mine = [phase["render"] / k, phase["accumulate"] / k, phase["resolve"] / k, phase["gather"] / k, phase["wall"] / k]
+    rank_rows = [mine]
+    if dist is not None:
+        rank_rows = [None] * N
+        dist.all_gather_object(rank_rows, mine)
 
     # per-rank kernel facts for the roofline object (rank 0's own kernel)
     n_spheres = sc.n
@@ -240,7 +300,8 @@ def main():
             np.save(os.environ["RT_BENCH_DUMP_LDR"], full)
         kernel_name = ("rt_trace_kernel<bounds hierarchy, 1024 threads, matrix-core top level + pooled descent, path cache>" if args.config == "c5"
                        else "rt_trace_kernel<LDS tables, 1024 threads, matrix-core filter, path cache>")
-        roofline, cull = roofline_object(cfg, kernel_name, avg_ms, avg_trav, n_spheres, kernel_sources_hash())
+        roofline, cull = roofline_object(cfg, kernel_name, avg_ms, avg_trav, n_spheres, kernel_sources_hash(), n_gpus=N)
+        per_rank, slowest = per_rank_report(rank_rows)
         out = {
             "metric": cfg["metric"],
             "value": value, "unit": "Msamples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
@@ -254,6 +315,9 @@ def main():
                        "traversals_per_sample": avg_trav / (W_IMG * rows * spp), "passes": st_last.passes},
             "roofline": roofline,
             "cull_factor": cull,
+            # labelled extra (north_star): rank 0's launch; `traffic` is only known for the profiled 1-GPU workload
+            "hbm_read_equivalent": hbm_read_equivalent(avg_ms, avg_trav, n_spheres, roofline.get("traffic")),
+            "per_rank": per_rank, "slowest_rank": slowest,
         }
         if N == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)

@@ -9,9 +9,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <array>
+#include <utility>
 #include <vector>
 
 #include "../../include/rt_api.h"
@@ -51,7 +54,10 @@ struct DevBuf {
         ptr = nullptr;
         count = 0;
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T));
-        if (e != hipSuccess) return Fail(RT_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();  // the failure is reported here; later hipGetLastError() checks must not see it again
+            return Fail(RT_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+        }
         count = n;
         return RT_OK;
     }
@@ -104,10 +110,10 @@ struct rt_ctx {
     bool useMfma = true;  // matrix-core pre-filter for the list scan (RT_SCAN=valu disables)
     bool matsInLds = true;   // RT_MATS_LDS=0 leaves the material table in global memory (frees 48 B/sphere of LDS)
     bool useRayCache = true;
+    bool useStash = true;  // regrouped hit processing through a per-wave hit stash (rt_kernels.h kStash); RT_STASH=0: off
     bool treeInLds = true;      // RT_TREE_LDS=0: the hierarchy's bounds are read through L2
     uint32_t treeTop = 128;  // largest top level the matrix-core filter takes (4 tiles of 32); RT_TREE_TOP overrides
     bool forceGlobal = false;
-    std::unordered_map<const void*, size_t> ldsAttr;  // dynamic-LDS limit last set per kernel variant (LaunchTrace)
 
     // work order of the tiles (BuildTileOrder): valid for the running accumulation's strip
     bool useTileOrder = true;  // RT_TILE_ORDER=0 keeps the image order
@@ -611,6 +617,20 @@ static void QueueShards(rtd::TraceParams& tp, uint32_t wavesLaunched, uint32_t q
     tp.dyn_blocks = (uint32_t)((total - begin + qb - 1) / qb);
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (device, function), process-wide: every kernel variant is raised
+// ONCE per device to the 160 KiB a workgroup can have, so that two contexts with different scenes can never disagree about it
+// (a per-context cache of "the last value I set" could skip the call after another context had lowered the limit), and a
+// launch-bound 1-spp frame pays the attribute call only the first time.
+static int RaiseLdsLimit(int device, const void* fn) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> raised;
+    std::lock_guard<std::mutex> lock(mu);
+    if (raised.count({device, fn})) return RT_OK;
+    RT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    raised.insert({device, fn});
+    return RT_OK;
+}
+
 // Launch the megakernel over total paths described by tp.  carryMode 0: ordinary launch.  1: probe -- RT_OK iff this scene
 // and these settings get the kernel variant that implements frame pipelining (nothing is launched).  2: launch that variant
 // (tp.ctl etc. filled by the caller; the queue cursor lives in tp.ctl and is reset by the preparation kernel).
@@ -656,14 +676,35 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     // per-wave caches of prepared paths go last, when there is room left (RT_RAY_CACHE=0 disables them)
     ldsBytes = (ldsBytes + 15) / 16 * 16;
     tp.ray_cache_off16 = 0;
-    if (ctx->useRayCache && ldsBytes + (size_t)wavesPerBlock * rtd::kRayCacheBytes <= 160 * 1024 / ctx->blocksPerCu) {
+    tp.ray_cache_stride16 = 0;
+    tp.stash_cap = 0;
+    // Hit stash (rt_kernels.h, kStash): the matrix-core variants at 1024 threads regroup their hit processing through a per-wave
+    // stash of up to 63 hit records in the room the path cache would take -- as many records as the LDS left over holds
+    // (RT_STASH=0: the path-cache variants; RT_STASH_CAP: fewer records).  depth shares its register with the scan entry.
+    bool useStash = false;
+    {
+        const size_t room = 160 * 1024 / ctx->blocksPerCu > ldsBytes ? (160 * 1024 / ctx->blocksPerCu - ldsBytes) / wavesPerBlock / 16 * 16 : 0;
+        uint32_t cap = (uint32_t)(room / (rtd::kStashDwords * 4));
+        cap = cap > 63u ? 63u : cap;
+        const uint32_t capEnv = EnvU32("RT_STASH_CAP", 63u);
+        cap = cap > capEnv ? capEnv : cap;
+        if (ctx->useStash && carryMode == 0 && (flat || tree) && ctx->blockThreads == 1024 && tp.max_depth < 65536u && cap >= 16u) {
+            useStash = true;
+            tp.stash_cap = cap;
+            tp.ray_cache_off16 = (uint32_t)(ldsBytes / 16);
+            tp.ray_cache_stride16 = (cap * rtd::kStashDwords * 4 + 15) / 16;
+            ldsBytes += (size_t)wavesPerBlock * tp.ray_cache_stride16 * 16;
+        }
+    }
+    if (!useStash && ctx->useRayCache && ldsBytes + (size_t)wavesPerBlock * rtd::kRayCacheBytes <= 160 * 1024 / ctx->blocksPerCu) {
         tp.ray_cache_off16 = (uint32_t)(ldsBytes / 16);
+        tp.ray_cache_stride16 = rtd::kRayCacheBytes / 16;
         ldsBytes += (size_t)wavesPerBlock * rtd::kRayCacheBytes;
     }
     if (std::getenv("RT_VERBOSE"))
-        std::fprintf(stderr, "rt_trace launch: tree=%d flat=%d ldsTables=%d blocks=%u threads=%u lds=%zu B (cand %zu, tables %zu, leaf %zu, ops %zu, sg %zu, tree %zu, cache %s)\n",
+        std::fprintf(stderr, "rt_trace launch: tree=%d flat=%d ldsTables=%d blocks=%u threads=%u lds=%zu B (cand %zu, tables %zu, leaf %zu, ops %zu, sg %zu, tree %zu, cache %s, stash %u)\n",
                      (int)tree, (int)flat, (int)ldsTables, blocks, ctx->blockThreads, ldsBytes, candBytes, ldsTables ? lds : (size_t)0, flat ? leafBytes : (size_t)0,
-                     (flat || tree) ? MfmaOpsBytesFor(topCnt) : (size_t)0, sgBytes, treeBytes, tp.ray_cache_off16 ? "yes" : "no");
+                     (flat || tree) ? MfmaOpsBytesFor(topCnt) : (size_t)0, sgBytes, treeBytes, (tp.ray_cache_off16 && !useStash) ? "yes" : "no", tp.stash_cap);
     // flat variant with the hit-processing tables provably in LDS (typed pointers: no flat loads) when they all fit
     const bool hitLds = flat && tp.mats_in_lds && (sgBytes != 0 || !tp.sg_enabled);
     if (carryMode != 0) {
@@ -674,11 +715,8 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
 #define RT_LAUNCH_K(KERNEL)                                                                                                   \
     do {                                                                                                                      \
         const void* fn_ = reinterpret_cast<const void*>(&KERNEL);                                                             \
-        size_t& set_ = ctx->ldsAttr[fn_];  /* the attribute call costs host time on launch-bound 1-spp frames: only on change */ \
-        if (ldsBytes > 48 * 1024 && set_ != ldsBytes) {                                                                       \
-            RT_HIP(hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));                      \
-            set_ = ldsBytes;                                                                                                  \
-        }                                                                                                                     \
+        /* the attribute belongs to the FUNCTION on this device, not to the context: raised once to what any launch can ask for, never lowered */ \
+        if (ldsBytes > 48 * 1024 && RaiseLdsLimit(ctx->device, fn_) != RT_OK) return RT_ERR_HIP;                               \
         hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(ctx->blockThreads), ldsBytes, ctx->stream, tp);                         \
     } while (0)
 #define RT_LAUNCH(LDS, T, M)                                                                        \
@@ -698,6 +736,10 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
         else RT_LAUNCH(LDS, 256, M);                                   \
     } while (0)
     if (carryMode == 2) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 1, true, true, true>));
+    else if (useStash && tree && tp.tree_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 2, true, true, false, true>));
+    else if (useStash && tree) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 2, true, false, false, true>));
+    else if (useStash && hitLds) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 1, true, true, false, true>));
+    else if (useStash) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 1, true, false, false, true>));
     else if (tree) RT_LAUNCH_T(false, 2);
     else if (flat) RT_LAUNCH_T(true, 1);
     else if (ldsTables) RT_LAUNCH_T(true, 0);
@@ -958,6 +1000,7 @@ int rt_create(int device_ordinal, rt_ctx** out) {
         ctx->matsInLds = EnvU32("RT_MATS_LDS", 1) != 0;
         ctx->useShadowGrid = EnvU32("RT_SHADOW_GRID", 1) != 0;
         ctx->useRayCache = EnvU32("RT_RAY_CACHE", 1) != 0;
+        ctx->useStash = EnvU32("RT_STASH", 1) != 0;
         ctx->treeInLds = EnvU32("RT_TREE_LDS", 1) != 0;
         ctx->useTileOrder = EnvU32("RT_TILE_ORDER", 1) != 0;
         ctx->treeTop = EnvU32("RT_TREE_TOP", 128);
@@ -1262,9 +1305,15 @@ int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, ui
     if (sppMax > sppPathCap) sppMax = sppPathCap;
     if (sppMax == 0) return Fail(RT_ERR_OUT_OF_MEMORY, "rt_render: workspace limit below one sample per pixel");
     const uint32_t sppTotal = s1 - s0;
-    const uint32_t sppPass = (uint32_t)(sppMax < sppTotal ? sppMax : sppTotal);
+    uint32_t sppPass = (uint32_t)(sppMax < sppTotal ? sppMax : sppTotal);
     int rc;
-    if ((rc = ctx->samples.Reserve((size_t)npix * sppPass * 3)) != RT_OK) return rc;
+    // The default limit is a snapshot of the free memory at rt_create; another context or the caller's allocator may have
+    // taken memory since.  A smaller sample buffer only means more passes (bit-identical: the accumulation stays sequential
+    // in s), so halve the pass until the buffer fits before giving up.
+    while ((rc = ctx->samples.Reserve((size_t)npix * sppPass * 3)) != RT_OK) {
+        if (rc != RT_ERR_OUT_OF_MEMORY || sppPass == 1u) return rc;
+        sppPass = (sppPass + 1u) / 2u;
+    }
 
     // Passes run back to back on the stream: trace(k) -> accumulate(k) -> trace(k+1) are ordered by the stream itself
     // (they share the sample buffer), so the host never waits between passes; each pass has its own three timing

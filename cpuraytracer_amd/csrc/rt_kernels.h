@@ -41,7 +41,12 @@
 
 namespace rtd {
 
-enum : uint32_t { kIdle = 0u, kNeedClosest = 1u, kNeedShadow = 2u };
+enum : uint32_t { kIdle = 0u, kNeedClosest = 1u, kNeedShadow = 2u, kHaveHit = 3u };  // kHaveHit: hit-stash variant only (below)
+
+// Hit stash (kStash variants of rt_trace_kernel): one record per closest hit that waits for its hit processing --
+// hit position, ray direction, throughput, radiance, stream state, sample slot, depth | scan entry << 16, traversals.
+// Field k of record r sits at dword k * cap + r of the wave's region: consecutive records, consecutive banks.
+constexpr uint32_t kStashDwords = 19;
 
 // Work-item index -> (column i, global row j, sample s) and the path's slot in the sample buffer: the explicit path
 // list of the unit tests, or the tiled order below over the rows of this shard.  slot = index either way.
@@ -235,10 +240,19 @@ RT_DEV bool claim_block(const TraceParams& p, SceneConsts* ldsK, uint32_t lane, 
 // 2 = matrix-core filter over the top level of the bounds hierarchy + per-lane descent (tables through L2).
 // kCarry: frame pipelining (rt_params.h): resume the paths the previous trace kernel carried out, end as soon as the
 // fresh queue is empty and carry the unfinished paths into the next kernel.
-template <bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds = false, bool kCarry = false>
+// kStash: REGROUPED HIT PROCESSING (within the wave).  Four closest-hit scans in ten end in the sky, so hit
+// processing -- Material::Scatter, the shadow index, DirectionalLight::Shade: 40 % of an iteration -- ran with 36 of 64
+// lanes.  Here a lane whose scan found a hit only RECORDS it (state kHaveHit: position in `ro`, scan entry in the high half
+// of `depth`) and the wave processes hits when at least stash_cap + 1 lanes hold one; with fewer it pushes them to a
+// per-wave stash in LDS (the region the prepared-path cache occupies in the other variants), all 64 lanes generate the next
+// 64 fresh paths straight into registers, scan, and the lanes that missed pop stashed hits until the wave is full of
+// hits.  Scans run with ~59 live rays, hit processing with ~58 lanes instead of 36.  Every path sees the same sequence of
+// operations on the same values as before: only WHEN a hit is processed changes, never what is computed.
+template <bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds = false, bool kCarry = false, bool kStash = false>
 __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams p) {
     constexpr bool kMfma = kScan != 0;
     static_assert(!kCarry || (kCache && kHitLds && kScan == 1), "frame pipelining is built for the flat LDS variant only");
+    static_assert(!kStash || (kCache && !kCarry), "the hit stash takes the LDS region of the prepared-path cache");
     static_assert(!kHitLds || kScan != 0, "kHitLds belongs to the matrix-core variants");
 #ifdef RT_TIMELINE
     const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz; diagnostic build only
@@ -342,7 +356,9 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         blkNext = b0 < p.total_paths ? b0 : p.total_paths;
         blkEnd = (b0 + kBlk * p.static_blocks) < p.total_paths ? (b0 + kBlk * p.static_blocks) : p.total_paths;
     }
-    float4* rayCache = kCache ? smem + p.ray_cache_off16 + (threadIdx.x / kWaveSize) * (kRayCacheBytes / 16) : nullptr;
+    // per-wave region behind the tables: the prepared-path cache, or (kStash) the hit stash, p.ray_cache_stride16 float4 per wave
+    float4* rayCache = kCache ? smem + p.ray_cache_off16 + (threadIdx.x / kWaveSize) * p.ray_cache_stride16 : nullptr;
+    uint32_t stashCnt = 0;  // kStash: records in the wave's stash (wave-uniform)
 
     unsigned long long dbgScan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef RT_TIMELINE
@@ -356,6 +372,101 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
 #ifdef RT_STAMPS
     unsigned long long cyRefill = 0, cyScan = 0, cyTrans = 0, cyIters = 0, cyHit[6] = {0, 0, 0, 0, 0, 0};
 #endif
+    // Next block of fresh paths for this wave; false when every shard is empty.  The block was claimed AHEAD, when the
+    // previous one was taken: the atomic's round trip (two of them with the look, ~4 us under load, 117 times per wave on
+    // C2) ran under the work on a whole block instead of stalling the wave.  A claim that came back beyond the shard's end
+    // falls through to a fresh look.
+    auto nextBlock = [&]() -> bool {
+        bool got = false;
+        if (pendShard < kQueueShards) {
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)pendCount);
+            const uint32_t b = c * kQueueShards + pendShard;
+            if (b < p.dyn_blocks) {
+                blkNext = p.dyn_begin + b * kBlk;
+                blkEnd = (blkNext + kBlk) < p.total_paths ? (blkNext + kBlk) : p.total_paths;
+                got = true;
+            } else {
+                mark_dry(ldsK, lane, pendShard);
+                pendShard = kQueueShards;  // that shard is dry
+            }
+        }
+        if (!got && !claim_block(p, ldsK, lane, kBlk, blkNext, blkEnd, pendShard)) return false;
+        // (not in the frame-pipelining kernel: a wave must start everything it owns before it may carry out)
+        if (kCarry) pendShard = kQueueShards;
+        if (pendShard < kQueueShards && ((dry_shards(ldsK) >> pendShard) & 1u)) pendShard = kQueueShards;
+        if (pendShard < kQueueShards && lane == 0) pendCount = atomicAdd(p.shard_heads + kShardStrideWords * pendShard, 1u);  // claim ahead
+        return true;
+    };
+    // A finished path: GetHitColor * exposureAdjustment, spheres-app.cpp:183; one 12-byte store
+    auto finishPath = [&]() {
+        const float expo = K.exposure;
+        *reinterpret_cast<float3*>(p.samples + (size_t)q * 3) = make_float3(rad.x * expo, rad.y * expo, rad.z * expo);
+        if (p.trav_out) p.trav_out[q] = pathTrav;
+        state = kIdle;
+#ifdef RT_TIMELINE
+        if (!kCarry && tlDrain != 0ull && gwave < 4096u) {
+            unsigned int* w = g_tlLast + 4u * gwave;
+            w[0] = tlBorn; w[1] = depth; w[2] = q; w[3] = pathTrav;
+        }
+#endif
+    };
+#ifdef RT_STAMPS
+    unsigned long long thA = 0, thB = 0;
+#endif
+    // Hit processing of one closest hit (scan entry idx at pos) for a lane in state kNeedClosest: Scatter, the shadow
+    // query, Emit + Shade, and the path's next state (GetHitColor, spheres-app.cpp:238-257).
+    auto processHit = [&](int idx, V3 pos, bool& finished) {
+        const float4 S = scanTab[idx];
+        const float radius = radTab[idx];  // radius and material tables are in scan-entry (clustered) order
+        const Mat m = load_material(matTab, idx);
+        const V3 center = v3(S.x, S.y, S.z);
+        const V3 nrm = div3(pos - center, radius);  // ray-tracing.cpp:58 (true divide; radius > 0)
+        V3 atten, local, localOcc, tex;
+        RT_STAMP(th0);
+        const bool scattered = scatter_only(m, rd, nrm, draws, atten, nextDir, tex, mt, K.sampler);  // Scatter first: it draws (spheres-app.cpp:246)
+        RT_STAMP(th1);
+        const bool cont = (depth < p.max_depth) && scattered;  // spheres-app.cpp:247
+        const bool useIndex = K.sg_enabled && dot3(pos, pos) <= K.sg_p0sq;
+        bool occluded = false;
+        if (useIndex) occluded = shadow_query(K, scanTab, sgCell, sgEntries, sgGlobal, pos, sunDir, aSun);
+        RT_STAMP(th2);
+        // the Blinn-Phong value (two normalisations, two pows) is only needed when the sun is visible or unknown
+        shade_value(K, m, tex, pos, nrm, !occluded, local, localOcc, mt);
+        RT_STAMP(th3);
+#ifdef RT_STAMPS
+        thA = th0;
+        thB = th3;
+#endif
+        RT_ACC(cyHit[0], th0, th1);
+        RT_ACC(cyHit[1], th1, th2);
+        RT_ACC(cyHit[2], th2, th3);
+        if (useIndex) {
+            // shadow ray answered by the exact footprint index: no second scan for this hit
+            ++nTrav;  // the shadow ray still counts as a traversal of the scene (matches the oracle's counter)
+            ++pathTrav;
+            if (!occluded) rad = rad + thr * local;           // radiance += throughput * (Emit + Shade)
+            else if (!scattered) rad = rad + thr * localOcc;  // occluded: throughput * (Emit + 0)
+            if (cont) {
+                thr = thr * atten;
+                ro = pos;
+                rd = nextDir;
+                ++depth;
+            } else {
+                finished = true;
+            }
+        } else {
+            pend = thr * local;
+            // a path that does not scatter ends here, so its nextDir registers carry throughput * (Emit + 0),
+            // the value the reference adds when the sun is occluded (0 for every non-emissive material)
+            pathScattered = scattered;
+            if (!scattered) nextDir = thr * localOcc;
+            contAfterShadow = cont;
+            thr = thr * atten;
+            ro = pos;  // shadow ray and scattered ray both start at hit.pos
+            rd = sunDir;
+            state = kNeedShadow;
+        }
+    };
     for (;;) {
         RT_STAMP(ts0);
         // ------------------------------------------------ refill idle lanes (ballot + prefix)
@@ -365,37 +476,106 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         // lanes), and an idle lane just pops a 48-byte slot.  In-flight paths are untouched: the generation only uses
         // temporaries.  Without room for the cache in LDS (kCache == false) idle lanes generate their own path.
         uint64_t idleMask = __ballot(state == kIdle);
-        if (kCache) {
+        if (kStash) {
+            float* stash = reinterpret_cast<float*>(rayCache);
+            const uint32_t cap = p.stash_cap;  // <= 63 records of kStashDwords dwords
+            // (1) idle lanes take stashed hits (newest first)
+            if (stashCnt != 0u && idleMask != 0ull) {
+                const uint32_t nIdle = (uint32_t)__popcll(idleMask);
+                const uint32_t n = stashCnt < nIdle ? stashCnt : nIdle;
+                const uint32_t r = prefix_count(idleMask);
+                if (state == kIdle && r < n) {
+                    const float* e = stash + (stashCnt - 1u - r);
+                    ro = v3(e[0], e[cap], e[2u * cap]);
+                    rd = v3(e[3u * cap], e[4u * cap], e[5u * cap]);
+                    thr = v3(e[6u * cap], e[7u * cap], e[8u * cap]);
+                    rad = v3(e[9u * cap], e[10u * cap], e[11u * cap]);
+                    draws.rng = Rng{__float_as_uint(e[12u * cap]), __float_as_uint(e[13u * cap]), __float_as_uint(e[14u * cap]),
+                                    __float_as_uint(e[15u * cap])};
+                    q = __float_as_uint(e[16u * cap]);
+                    depth = __float_as_uint(e[17u * cap]);
+                    pathTrav = __float_as_uint(e[18u * cap]);
+                    state = kHaveHit;
+                }
+                stashCnt -= n;
+            }
+            // (2) process the hits when (nearly) every lane holds one; with fewer and nothing to scan, make room for 64 fresh paths
+            const uint64_t hitMask = __ballot(state == kHaveHit);
+            const uint32_t nHit = (uint32_t)__popcll(hitMask);
+            bool process = nHit > cap;
+            if (!process && nHit != 0u && __ballot(state == kNeedClosest || state == kNeedShadow) == 0ull) {
+                if (blkNext == blkEnd && !queueEmpty && !nextBlock()) queueEmpty = true;
+                if (blkNext == blkEnd) {
+                    process = true;  // no fresh paths left: the hits are processed as they are
+                } else {
+                    // (the stash is empty here: had records been left after (1), no lane would be idle, so with nothing to
+                    // scan all 64 would hold a hit)
+                    wave_lds_handoff();  // the pops above have read their records
+                    if (state == kHaveHit) {
+                        float* e = stash + prefix_count(hitMask);
+                        e[0] = ro.x; e[cap] = ro.y; e[2u * cap] = ro.z;
+                        e[3u * cap] = rd.x; e[4u * cap] = rd.y; e[5u * cap] = rd.z;
+                        e[6u * cap] = thr.x; e[7u * cap] = thr.y; e[8u * cap] = thr.z;
+                        e[9u * cap] = rad.x; e[10u * cap] = rad.y; e[11u * cap] = rad.z;
+                        e[12u * cap] = __uint_as_float(draws.rng.s0); e[13u * cap] = __uint_as_float(draws.rng.s1);
+                        e[14u * cap] = __uint_as_float(draws.rng.s2); e[15u * cap] = __uint_as_float(draws.rng.s3);
+                        e[16u * cap] = __uint_as_float(q);
+                        e[17u * cap] = __uint_as_float(depth);
+                        e[18u * cap] = __uint_as_float(pathTrav);
+                        state = kIdle;
+                    }
+                    stashCnt = nHit;
+                    wave_lds_handoff();  // records are popped by other lanes than the ones that pushed them
+                }
+            }
+            if (process) {
+                bool finished = false;
+                if (state == kHaveHit) {
+                    const int hidx = (int)(depth >> 16);
+                    depth &= 0xffffu;
+                    state = kNeedClosest;
+                    processHit(hidx, ro, finished);
+                }
+                if (finished) finishPath();
+            }
+            // (3) fresh paths: whenever every lane is idle -- at the start and after each push -- all 64 lanes generate the
+            // next 64 paths of the wave's queue block straight into their registers (index arithmetic, stream seeding,
+            // Camera::GetRay with its two normalisations at full lane utilisation, no LDS round trip)
+            if (__ballot(state != kIdle) == 0ull) {
+                if (blkNext == blkEnd && !queueEmpty && !nextBlock()) queueEmpty = true;
+                if (blkNext != blkEnd) {
+#ifdef RT_TIMELINE
+                    if (blkNext % kBlk == 0u) {
+                        tlLastClaim = __builtin_amdgcn_s_memrealtime();
+                        ++tlBlocks;
+                        tlLastBlock = blkNext / kBlk;
+                    }
+#endif
+                    const uint32_t nGen = (blkEnd - blkNext) < (uint32_t)kWaveSize ? (blkEnd - blkNext) : (uint32_t)kWaveSize;
+                    if (lane < nGen) {
+                        uint32_t i, j, sN;
+                        path_coordinates(p, blkNext + lane, i, j, sN, q);
+                        draws.rng = rng_seed(p.seed, j * p.W + i, sN);
+                        gen_primary_ray(K, i, j, sN, ro, rd);
+                        thr = v3(1.f, 1.f, 1.f);
+                        rad = v3(0.f, 0.f, 0.f);
+                        depth = 0;
+                        pathTrav = 0;
+                        state = kNeedClosest;
+#ifdef RT_TIMELINE
+                        tlBorn = (uint32_t)(__builtin_amdgcn_s_memrealtime() - tl0);
+#endif
+                    }
+                    blkNext += nGen;
+                }
+            }
+        } else if (kCache) {
             while (idleMask != 0ull) {
                 if (cachePos == cacheCnt) {
                     if (queueEmpty) break;
-                    if (blkNext == blkEnd) {
-                        // The next block was claimed AHEAD, when this one was taken: the atomic's round trip (two of them with the
-                        // look, ~4 us under load, 117 times per wave on C2) ran under the work on a whole block instead of
-                        // stalling the wave.  A claim that came back beyond the shard's end falls through to a fresh look.
-                        bool got = false;
-                        if (pendShard < kQueueShards) {
-                            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)pendCount);
-                            const uint32_t b = c * kQueueShards + pendShard;
-                            if (b < p.dyn_blocks) {
-                                blkNext = p.dyn_begin + b * kBlk;
-                                blkEnd = (blkNext + kBlk) < p.total_paths ? (blkNext + kBlk) : p.total_paths;
-                                got = true;
-                            } else {
-                                mark_dry(ldsK, lane, pendShard);
-                                pendShard = kQueueShards;  // that shard is dry
-                            }
-                        }
-                        if (!got) {
-                            if (!claim_block(p, ldsK, lane, kBlk, blkNext, blkEnd, pendShard)) {
-                                queueEmpty = true;
-                                break;
-                            }
-                        }
-                        // (not in the frame-pipelining kernel: a wave must start everything it owns before it may carry out)
-                        if (kCarry) pendShard = kQueueShards;
-                        if (pendShard < kQueueShards && ((dry_shards(ldsK) >> pendShard) & 1u)) pendShard = kQueueShards;
-                        if (pendShard < kQueueShards && lane == 0) pendCount = atomicAdd(p.shard_heads + kShardStrideWords * pendShard, 1u);  // claim ahead
+                    if (blkNext == blkEnd && !nextBlock()) {
+                        queueEmpty = true;
+                        break;
                     }
 #ifdef RT_TIMELINE
                     if (blkNext % kBlk == 0u) {
@@ -477,7 +657,12 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                 idleMask = __ballot(state == kIdle);
             }
         }
-        if (__ballot(state != kIdle) == 0ull) break;  // queue empty and every lane drained
+        if (__ballot(state != kIdle) == 0ull) {
+            // queue empty and every lane drained -- but hits may still wait in the stash: a wave of 64 hits whose paths ALL
+            // ended at that hit (a tile looking at an emissive sphere) leaves every lane idle with records behind it
+            if (kStash && stashCnt != 0u) continue;  // back to the top: the idle lanes pop them (at most 63: one more round)
+            break;
+        }
 #ifdef RT_TIMELINE
         ++tlIters;
         if (queueEmpty && cachePos == cacheCnt) {
@@ -524,15 +709,16 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         // ------------------------------------------------ one list scan for every live lane
         float tmin = 0.f;
         int idx = -1;
+        const bool live = kStash ? (state == kNeedClosest || state == kNeedShadow) : (state != kIdle);  // (lanes holding a hit wait)
         if (kMfma) {
             // every lane takes part: lane l also supplies operands for, and filters half the spheres of,
             // the ray owned by lane l^32, whether or not its own ray is live
             scan_list_mfma<kScan == 2>(scanTab, leafTab, origTab, mfmaOps, nTiles, nTop, treeTab, p.level_off, p.n_levels, p.bound_norm, p.single_mask, p.n_always, p.tree_box_on ? p.tree_box : nullptr, ro, rd,
-                                       state != kIdle, tmin, idx, waveCand, lane, dbgScan);
-        } else if (state != kIdle) {
+                                       live, tmin, idx, waveCand, lane, dbgScan);
+        } else if (live) {
             scan_list_deferred(scanTab, origTab, p.n_padded, ro, rd, tmin, idx, cand);
         }
-        if (state != kIdle) {
+        if (live) {
             ++nTrav;
             ++pathTrav;
         }
@@ -541,7 +727,8 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         // ------------------------------------------------ state transitions
         bool finished = false;
 #ifdef RT_STAMPS
-        unsigned long long thA = 0, thB = 0;
+        thA = 0;
+        thB = 0;
 #endif
         if (state == kNeedClosest) {
             ++nSeg;
@@ -550,58 +737,14 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                 const V3 sky = v3(K.sky_emit[0], K.sky_emit[1], K.sky_emit[2]);
                 rad = rad + thr * sky;
                 finished = true;
+            } else if (kStash) {
+                // the hit waits for a full wave of hits: position (XMVectorMultiplyAdd(t, dir, origin), ray-tracing.cpp:57) in
+                // place of the origin, scan entry beside the depth
+                ro = tmin * rd + ro;
+                depth |= (uint32_t)idx << 16;
+                state = kHaveHit;
             } else {
-                const float4 S = scanTab[idx];
-                const float radius = radTab[idx];  // radius and material tables are in scan-entry (clustered) order
-                const Mat m = load_material(matTab, idx);
-                const V3 center = v3(S.x, S.y, S.z);
-                const V3 pos = tmin * rd + ro;          // XMVectorMultiplyAdd(t, dir, origin), ray-tracing.cpp:57
-                const V3 nrm = div3(pos - center, radius);  // ray-tracing.cpp:58 (true divide; radius > 0)
-                V3 atten, local, localOcc, tex;
-                RT_STAMP(th0);
-                const bool scattered = scatter_only(m, rd, nrm, draws, atten, nextDir, tex, mt, K.sampler);  // Scatter first: it draws (spheres-app.cpp:246)
-                RT_STAMP(th1);
-                const bool cont = (depth < p.max_depth) && scattered;  // spheres-app.cpp:247
-                const bool useIndex = K.sg_enabled && dot3(pos, pos) <= K.sg_p0sq;
-                bool occluded = false;
-                if (useIndex) occluded = shadow_query(K, scanTab, sgCell, sgEntries, sgGlobal, pos, sunDir, aSun);
-                RT_STAMP(th2);
-                // the Blinn-Phong value (two normalisations, two pows) is only needed when the sun is visible or unknown
-                shade_value(K, m, tex, pos, nrm, !occluded, local, localOcc, mt);
-                RT_STAMP(th3);
-#ifdef RT_STAMPS
-                thA = th0;
-                thB = th3;
-#endif
-                RT_ACC(cyHit[0], th0, th1);
-                RT_ACC(cyHit[1], th1, th2);
-                RT_ACC(cyHit[2], th2, th3);
-                if (useIndex) {
-                    // shadow ray answered by the exact footprint index: no second scan for this hit
-                    ++nTrav;  // the shadow ray still counts as a traversal of the scene (matches the oracle's counter)
-                    ++pathTrav;
-                    if (!occluded) rad = rad + thr * local;           // radiance += throughput * (Emit + Shade)
-                    else if (!scattered) rad = rad + thr * localOcc;  // occluded: throughput * (Emit + 0)
-                    if (cont) {
-                        thr = thr * atten;
-                        ro = pos;
-                        rd = nextDir;
-                        ++depth;
-                    } else {
-                        finished = true;
-                    }
-                } else {
-                    pend = thr * local;
-                    // a path that does not scatter ends here, so its nextDir registers carry throughput * (Emit + 0),
-                    // the value the reference adds when the sun is occluded (0 for every non-emissive material)
-                    pathScattered = scattered;
-                    if (!scattered) nextDir = thr * localOcc;
-                    contAfterShadow = cont;
-                    thr = thr * atten;
-                    ro = pos;  // shadow ray and scattered ray both start at hit.pos
-                    rd = sunDir;
-                    state = kNeedShadow;
-                }
+                processHit(idx, tmin * rd + ro, finished);  // XMVectorMultiplyAdd(t, dir, origin), ray-tracing.cpp:57
             }
         } else if (state == kNeedShadow) {
             if (idx < 0) rad = rad + pend;              // sun visible: radiance += throughput * (Emit + Shade)
@@ -614,19 +757,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                 finished = true;
             }
         }
-        if (finished) {
-            // GetHitColor * exposureAdjustment, spheres-app.cpp:183; one 12-byte store
-            const float expo = K.exposure;
-            *reinterpret_cast<float3*>(p.samples + (size_t)q * 3) = make_float3(rad.x * expo, rad.y * expo, rad.z * expo);
-            if (p.trav_out) p.trav_out[q] = pathTrav;
-            state = kIdle;
-#ifdef RT_TIMELINE
-            if (!kCarry && tlDrain != 0ull && gwave < 4096u) {
-                unsigned int* w = g_tlLast + 4u * gwave;
-                w[0] = tlBorn; w[1] = depth; w[2] = q; w[3] = pathTrav;
-            }
-#endif
-        }
+        if (finished) finishPath();
         RT_STAMP(ts3);
 #ifdef RT_STAMPS
         if (thA != 0) {  // lanes that processed a hit this iteration (uniform enough: lane 0 reports)
@@ -854,9 +985,10 @@ __global__ void __launch_bounds__(256) rt_accumulate_kernel(const float* __restr
 
 // ================================================== ordered accumulation of pipelined regions (A16)
 // Frame pipelining: add every region that is complete -- sequence numbers committed+1 .. min(newest, oldest_open - 1) -- to
-// the HDR strip, region by region and sample by sample in increasing s (spheres-app.cpp:182-183), then let the block that
-// finishes last publish the new commit point.  Every block reads the same committed_seq / oldest_open: they are only
-// written by that last block and by the trace kernel before this one.
+// the HDR strip, region by region and sample by sample in increasing s (spheres-app.cpp:182-183).  The commit point is kept
+// TWICE (FrameCtl): commit kernel number k reads entry k & 1 and its block 0 writes the new point to entry (k + 1) & 1, which
+// nobody reads before the next commit kernel -- no closing ticket, no "last block".  Every block therefore reads the same
+// committed_seq / oldest_open: the entry it reads is not written during this kernel, oldest_open only by the trace kernels.
 struct RegionTable {
     uint32_t seq[kMaxFramesInFlight];  // by ring slot (sequence % regions): the call that owns it
     uint32_t spp[kMaxFramesInFlight];  // ... and its samples per pixel

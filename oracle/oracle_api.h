@@ -11,7 +11,10 @@ extern "C" {
 
 typedef struct orc_ctx orc_ctx;
 
-enum { ORC_ACCEL_LIST = 0, ORC_ACCEL_BVH = 1 };
+/* LIST: Sphere::Intersect over the whole list -- the contract.  BVH: the reference's BvhNode (its slab test loses grazing hits
+   the list finds, ~2 in 10^7 paths on 10^4 spheres).  PADDED_LIST: the list scan's result, found through a tree with
+   provably conservative (padded, binary64) boxes -- what the full-size differentials use (rt_oracle.h PaddedListTree). */
+enum { ORC_ACCEL_LIST = 0, ORC_ACCEL_BVH = 1, ORC_ACCEL_PADDED_LIST = 2 };
 
 int orc_create(orc_ctx** out);
 void orc_destroy(orc_ctx* ctx);
@@ -35,6 +38,7 @@ void orc_set_sampler(uint32_t flags);
 /* CPU-only diagnostic: GetHitColor in the reference's nesting L = (E+S) + a*(...) (spheres-app.cpp:249-251) instead of
  * the forward radiance += throughput*(E+S) form that the path's contract (and the HIP kernel) uses */
 void orc_use_nested_radiance(int on);
+void orc_use_reference_bvh_tie_rule(int on);  /* CPU diagnostic: exact ties go to the BVH's right child (the reference's rule) */
 int orc_clear(orc_ctx* ctx);
 int orc_resolve(orc_ctx* ctx, uint32_t n_samples);
 int orc_download(orc_ctx* ctx, float* hdr_rgb, uint8_t* ldr_rgb);
@@ -53,6 +57,11 @@ int orc_unit_primary_rays(orc_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* 
 int orc_unit_closest_hit(orc_ctx* ctx, const float* rays, uint32_t n, int accel, float* out_hits);
 int orc_unit_trace(orc_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* ijs, uint32_t n, uint32_t max_depth, uint64_t seed,
                    int accel, float* out_rgb, uint32_t* out_traversals);
+/* Diagnostic: one sample's path with every accelerator query recorded -- 8 floats per query: origin xyz, direction xyz, kind
+   (0 closest hit, 1 sun occlusion), result (closest: t or -1 for a miss; occlusion: 1 occluded, 0 visible).  *n_queries = queries
+   made (only the first `cap` are stored). */
+int orc_unit_trace_path(orc_ctx* ctx, uint32_t W, uint32_t H, uint32_t i, uint32_t j, uint32_t s, uint32_t max_depth, uint64_t seed,
+                        int accel, float* out_queries, uint32_t cap, uint32_t* n_queries, float out_rgb[3]);
 float orc_fresnel_term(float cos_incident, float ior);
 void orc_refract(const float incident[3], const float normal[3], float eta, float out[3]);
 void orc_reflect(const float incident[3], const float normal[3], float out[3]);

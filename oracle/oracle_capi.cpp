@@ -59,6 +59,9 @@ int orc_scene_upload(orc_ctx* ctx, const rt_sphere* spheres, const rt_material* 
     return 0;
 }
 
+static SpheresApp::Accel AccelOf(int accel) {
+    return accel == ORC_ACCEL_BVH ? SpheresApp::Accel::Bvh : (accel == ORC_ACCEL_PADDED_LIST ? SpheresApp::Accel::PaddedList : SpheresApp::Accel::List);
+}
 int orc_render(orc_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1, uint32_t max_depth, uint64_t seed,
                int accel, int threads, rt_stats* out_stats) {
     if (!ctx || W == 0 || H == 0 || s1 <= s0 || s0 == 0) return Fail("orc_render: invalid argument");
@@ -68,7 +71,7 @@ int orc_render(orc_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, 
     if (s0 == 1) ctx->app.Clear();
     else if (ctx->app.SampleCount() + 1 != s0) return Fail("orc_render: sample range does not continue the accumulation");
     RenderCounters rc;
-    ctx->app.Render(W, H, rs, s0, s1, max_depth, seed, accel == ORC_ACCEL_BVH ? SpheresApp::Accel::Bvh : SpheresApp::Accel::List,
+    ctx->app.Render(W, H, rs, s0, s1, max_depth, seed, AccelOf(accel),
                     threads, rc);
     if (out_stats) {
         std::memset(out_stats, 0, sizeof(*out_stats));
@@ -84,6 +87,7 @@ int orc_render(orc_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, 
 void orc_use_reference_halton_counters(int on) { Random::UseReferenceHaltonCounters(on != 0); }
 void orc_set_sampler(uint32_t flags) { Random::SetSamplerFlags(flags); }
 void orc_use_nested_radiance(int on) { UseNestedRadiance(on != 0); }
+void orc_use_reference_bvh_tie_rule(int on) { UseReferenceBvhTieRule(on != 0); }
 
 int orc_clear(orc_ctx* ctx) {
     if (!ctx) return Fail("orc_clear: null ctx");
@@ -169,7 +173,7 @@ int orc_unit_closest_hit(orc_ctx* ctx, const float* rays, uint32_t n, int accel,
         const float* r = rays + 6 * k;
         Ray ray{XMVectorSet(r[0], r[1], r[2], 1.f), XMVectorSet(r[3], r[4], r[5], 0.f)};
         float* o = out_hits + 10 * k;
-        const auto hit = ctx->app.ClosestHitWith(ray, accel == ORC_ACCEL_BVH ? SpheresApp::Accel::Bvh : SpheresApp::Accel::List);
+        const auto hit = ctx->app.ClosestHitWith(ray, AccelOf(accel));
         if (hit) {
             const Payload& p = *hit;
             int32_t idx = p.index;
@@ -192,10 +196,23 @@ int orc_unit_trace(orc_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* ijs, ui
     for (uint32_t k = 0; k < n; ++k) {
         uint32_t trav = 0;
         const XMVECTOR c = ctx->app.TraceSample(W, H, ijs[3 * k], ijs[3 * k + 1], ijs[3 * k + 2], max_depth, seed,
-                                                accel == ORC_ACCEL_BVH ? SpheresApp::Accel::Bvh : SpheresApp::Accel::List, &trav);
+                                                AccelOf(accel), &trav);
         out_rgb[3 * k] = c.x; out_rgb[3 * k + 1] = c.y; out_rgb[3 * k + 2] = c.z;
         if (out_traversals) out_traversals[k] = trav;
     }
+    return 0;
+}
+int orc_unit_trace_path(orc_ctx* ctx, uint32_t W, uint32_t H, uint32_t i, uint32_t j, uint32_t s, uint32_t max_depth, uint64_t seed, int accel,
+                        float* out_queries, uint32_t cap, uint32_t* n_queries, float out_rgb[3]) {
+    if (!ctx || !ctx->app.HasScene()) return Fail("orc_unit_trace_path: no scene");
+    std::vector<float> rays;
+    const XMVECTOR c = ctx->app.TraceSampleRecorded(W, H, i, j, s, max_depth, seed,
+                                                    AccelOf(accel), rays);
+    const uint32_t n = (uint32_t)(rays.size() / 8);
+    if (n_queries) *n_queries = n;
+    for (uint32_t k = 0; k < n && k < cap; ++k)
+        for (int q = 0; q < 8; ++q) out_queries[8 * k + q] = rays[8 * (size_t)k + q];
+    if (out_rgb) { out_rgb[0] = c.x; out_rgb[1] = c.y; out_rgb[2] = c.z; }
     return 0;
 }
 float orc_fresnel_term(float c, float ior) { return FresnelTerm1(c, ior); }

@@ -49,7 +49,7 @@ MATERIAL_DTYPE = np.dtype([("type", "<u4"), ("tex_type", "<u4"), ("smoothness", 
 assert SPHERE_DTYPE.itemsize == 16 and MATERIAL_DTYPE.itemsize == 48
 assert C.sizeof(RtSphere) == 16 and C.sizeof(RtMaterial) == 48 and C.sizeof(RtCamera) == 72 and C.sizeof(RtLight) == 28
 
-ACCEL_LIST, ACCEL_BVH = 0, 1
+ACCEL_LIST, ACCEL_BVH, ACCEL_PADDED_LIST = 0, 1, 2
 
 
 def build(force=False):
@@ -110,6 +110,8 @@ def lib():
         L.orc_set_sampler.restype = None
         L.orc_use_nested_radiance.argtypes = [C.c_int]
         L.orc_use_nested_radiance.restype = None
+        L.orc_use_reference_bvh_tie_rule.argtypes = [C.c_int]
+        L.orc_use_reference_bvh_tie_rule.restype = None
         L.orc_clear.argtypes = [C.c_void_p]
         L.orc_resolve.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -121,6 +123,8 @@ def lib():
         L.orc_unit_closest_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_unit_trace.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64,
                                      C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_unit_trace_path.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                          C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
         L.orc_refract.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float)]
         L.orc_reflect.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_unit_scatter.argtypes = [C.POINTER(RtMaterial), C.POINTER(C.c_float), C.POINTER(C.c_float),
@@ -235,6 +239,18 @@ class Oracle:
         _check(lib().orc_unit_trace(self._h, W, H, ijs.ctypes.data, ijs.shape[0], max_depth, seed, accel, rgb.ctypes.data,
                                     trav.ctypes.data))
         return rgb, trav
+
+
+def _trace_path(self, W, H, i, j, s, max_depth, seed, accel=ACCEL_LIST, cap=256):
+    """Diagnostic: every accelerator query of one sample's path, [n, 8] = origin, direction, kind (0 closest / 1 occlusion), result."""
+    out = np.zeros((cap, 8), dtype=np.float32)
+    n = C.c_uint32(0)
+    rgb = (C.c_float * 3)()
+    _check(lib().orc_unit_trace_path(self._h, W, H, i, j, s, max_depth, seed, accel, out.ctypes.data, cap, C.byref(n), rgb))
+    return out[:min(cap, n.value)], np.array(list(rgb), dtype=np.float32)
+
+
+Oracle.trace_path = _trace_path
 
 
 def halton_array(index, base):

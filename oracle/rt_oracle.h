@@ -94,6 +94,8 @@ uint32_t ScriptDrawsUsed();
 // CPU-only diagnostic: evaluate GetHitColor in the reference's own nesting (spheres-app.cpp:249-251) instead of the
 // forward throughput form that is the path's contract (see GetHitColorNested in rt_oracle.cpp).
 void UseNestedRadiance(bool on);
+// CPU-only diagnostic: BvhNode::Intersect gives exact ties to the right child, as the reference does (see rt_oracle.cpp).
+void UseReferenceBvhTieRule(bool on);
 bool NestedRadiance();
 
 // ------------------------------------------------------------------ geometry
@@ -297,6 +299,36 @@ struct FlatScene {
 // BASELINE configs' synthetic scenes.  name: "cover", "three", "grid10k".
 bool BuildNamedScene(const char* name, uint64_t seed, float aspect, float apertureOverride /*<0: default*/, FlatScene& out);
 
+// ------------------------------------------------------------- list scan, accelerated (oracle infrastructure)
+// The path's contract is the LIST scan: Sphere::Intersect for every sphere, smallest t, ties to the lower index
+// (SURVEY.md §8a A6).  The reference's BvhNode is not that function: its slab test (BoundingBox::Intersects in binary32) and
+// the sphere test (also binary32, with a discriminant that is off by up to 16 eps a G far from the origin) disagree about
+// grazing rays, so on the 10,004-sphere scene BvhNode loses about 2 hits in 10^7 paths that the list finds (and an exact tie
+// goes to whichever sphere the random tree puts right).  Running the list itself on 10^9 paths x 10^4 spheres is out of
+// reach, so the full-size differentials use THIS accelerator: a median-split tree over the same spheres whose boxes are
+// padded, per ray, by more than any accepted root's hit point can lie outside its sphere -- the discriminant's error bound
+// E <= 16 eps a G, G = 2|o|^2 + 2(|c|+r)^2 + r^2, puts that point within sqrt(2E/a) of the surface; the padding is
+// sqrt(128 eps G_node) with G_node from the node's largest |c|+r and r (four times the bound), and the slab test runs in
+// binary64 over the forward half-line.  Every sphere whose reference-order test accepts a root is therefore visited, each
+// visited sphere is tested by Sphere::Intersect itself, and the merge is the list's (smaller t, then lower index): the result
+// IS the list scan's.  tests/test_oracle_units.py checks it against the plain list on grazing and random rays.
+struct PaddedListTree : public Hitable {
+    struct Node {
+        double lo[3], hi[3];
+        double reach, rmax;  // max |c| + r and max r over the node's spheres
+        int left, right;     // children, or -1
+        int sphere;          // leaf: index into spheres
+    };
+    std::vector<Node> nodes;
+    std::vector<const Sphere*> spheres;
+    explicit PaddedListTree(const std::vector<const Sphere*>& list);
+    AABB GetAABB() const override { return AABB{}; }
+    bool Intersect(const Ray& ray, Payload& payload) const override;
+
+private:
+    int Build(std::vector<int>& ids, int begin, int end);
+};
+
 // ------------------------------------------------------------- headless SpheresApp
 struct RenderCounters {
     uint64_t samples = 0, traversals = 0, segments = 0;
@@ -304,7 +336,8 @@ struct RenderCounters {
 
 class SpheresApp {  // spheres-app.h:15-43, minus the Win32/D2D members
 public:
-    enum class Accel { List, Bvh };
+    enum class Accel { List, Bvh, PaddedList };
+    const Hitable* AccelFor(Accel a) const;
     void LoadScene(const FlatScene& flat, uint64_t bvhAxisSeed);
 
     // GenerateRays for one pixel (spheres-app.cpp:132-161): sample index s is 1-based (:168).
@@ -325,6 +358,8 @@ public:
     static XMCOLOR TonemapColor(const XMVECTOR& hdrColor, uint32_t n);
     XMVECTOR TraceSample(uint32_t W, uint32_t H, uint32_t i, uint32_t j, uint32_t s, uint32_t maxDepth, uint64_t seed,
                          Accel accel, uint32_t* traversals) const;
+    XMVECTOR TraceSampleRecorded(uint32_t W, uint32_t H, uint32_t i, uint32_t j, uint32_t s, uint32_t maxDepth, uint64_t seed,
+                                 Accel accel, std::vector<float>& rays) const;
 
     const std::vector<XMVECTOR>& Hdr() const { return m_backbufferHdr; }
     const std::vector<XMCOLOR>& Ldr() const { return m_backbufferLdr; }
@@ -340,6 +375,7 @@ private:
     std::vector<std::unique_ptr<Texture>> m_textures;
     std::vector<std::unique_ptr<Light>> m_lights;
     std::unique_ptr<BvhNode> m_bvh;
+    std::unique_ptr<PaddedListTree> m_paddedList;
     std::unique_ptr<Material> m_skyMaterial;
     float m_exposureScale = 0.f;
     uint32_t m_sampleCount = 0;

@@ -264,7 +264,7 @@ def test_grid10k_scene_descends_the_bounds_hierarchy(hip, oracle, scenes_mod):
     orc.upload(sc)
     sg = hip.render(64, 64, 1, 2, 50, 1)
     hg, _ = hip.download(ldr=False)
-    so = orc.render(64, 64, 1, 2, 50, 1, accel=oracle.ACCEL_BVH, threads=8)
+    so = orc.render(64, 64, 1, 2, 50, 1, accel=oracle.ACCEL_PADDED_LIST, threads=8)
     ho, _ = orc.download()
     assert_same(hg, ho, "grid10k HDR")
     assert sg.traversals == so.traversals
@@ -276,7 +276,7 @@ def test_grid10k_scene_descends_the_bounds_hierarchy(hip, oracle, scenes_mod):
     hip.upload(sc2)
     orc.upload(sc2)
     rg, tg = hip.unit_trace(4096, 4096, ijs, 50, 1)
-    ro, to = orc.trace(4096, 4096, ijs, 50, 1, accel=oracle.ACCEL_BVH)
+    ro, to = orc.trace(4096, 4096, ijs, 50, 1, accel=oracle.ACCEL_PADDED_LIST)
     assert_same(rg, ro, "C5 per-sample radiance")
     assert np.array_equal(tg, to)
 
@@ -341,7 +341,7 @@ def _assert_image_equals_oracle(hip, oracle, sc, W, H, spp, depth, seed=3):
     orc.upload(sc)
     sg = hip.render(W, H, 1, 1 + spp, depth, seed)
     hg, _ = hip.download(ldr=False)
-    so = orc.render(W, H, 1, 1 + spp, depth, seed, accel=oracle.ACCEL_BVH, threads=8)
+    so = orc.render(W, H, 1, 1 + spp, depth, seed, accel=oracle.ACCEL_PADDED_LIST, threads=8)
     ho, _ = orc.download()
     assert_same(hg, ho, "custom scene HDR")
     assert sg.traversals == so.traversals and sg.segments == so.segments
@@ -473,9 +473,9 @@ def _fuzz_case(hip, oracle, seed, n, scale, offset):
     ijs = np.stack([rng.integers(0, W, m), rng.integers(0, H, m), rng.integers(1, 600, m)], 1).astype(np.uint32)
     rays = orc.primary_rays(W, H, ijs)
     assert_same(hip.unit_primary_rays(W, H, ijs), rays, "primary rays")
-    assert_same(hip.unit_closest_hit(rays), orc.closest_hit(rays, oracle.ACCEL_BVH), "closest hits")
+    assert_same(hip.unit_closest_hit(rays), orc.closest_hit(rays, oracle.ACCEL_PADDED_LIST), "closest hits")
     rg, tg = hip.unit_trace(W, H, ijs, 30, 77 + seed)
-    ro, to = orc.trace(W, H, ijs, 30, 77 + seed, accel=oracle.ACCEL_BVH)
+    ro, to = orc.trace(W, H, ijs, 30, 77 + seed, accel=oracle.ACCEL_PADDED_LIST)
     assert_same(rg, ro, "per-sample radiance")
     assert np.array_equal(tg, to)
     assert np.isfinite(rg).all()
@@ -487,6 +487,19 @@ def test_random_scene_images_equal_the_oracle_render(hip, oracle, seed, n, W, H,
     accumulation and the counters are on the path): HDR strip, traversal and segment counts equal the oracle's render."""
     sc, _ = _fuzz_scene(oracle, seed, n, 1.0, (0.0, 0.0, 0.0))
     _assert_image_equals_oracle(hip, oracle, sc, W, H, spp, 20, seed=9 + seed)
+
+
+@pytest.mark.parametrize("W,H,spp,cx", [(256, 64, 2, 0.0), (256, 64, 2, 1.1), (403, 37, 3, -0.9), (64, 8, 5, 0.6)])
+def test_hits_left_in_the_stash_when_every_lane_finishes_are_not_lost(hip, oracle, W, H, spp, cx):
+    """Regression (round 3, hit stash): a wave whose 64 processed hits ALL end their paths (a tile looking at an Emissive
+    sphere: no scatter) falls idle while earlier hits still wait in its stash; with no fresh paths left it used to leave the
+    loop and lose them (missing samples, missing shadow traversals).  An emissive sphere that covers most, all, or part of
+    every 64-pixel tile, few enough paths that every wave only has its static block."""
+    centers = np.array([[cx, 0.0, 0.0], [0.0, -101.0, 0.0], [2.5, 0.0, 0.5]], dtype=np.float32)
+    radii = np.array([1.0, 100.0, 0.5], dtype=np.float32)
+    sc = _custom_scene(oracle, centers, radii, np.array([3, 0, 1], dtype=np.uint32), (0.0, 0.3, -4.0), (0.0, 0.0, 0.0), 35.0, W / float(H))
+    sc.materials["luminance"] = np.array([5000.0, 0.0, 0.0], dtype=np.float32)
+    _assert_image_equals_oracle(hip, oracle, sc, W, H, spp, 12, seed=5)
 
 
 # ------------------------------------------- properties at BASELINE.json's full size (C2)
@@ -598,13 +611,13 @@ def test_c4_full_size_depth_of_field(hip, oracle, scenes_mod):
     n = 1200
     ijs = np.stack([rng.integers(0, 1920, n), rng.integers(0, 1080, n), rng.integers(1, 513, n)], 1).astype(np.uint32)
     rg, tg = hip.unit_trace(1920, 1080, ijs, 50, 1)
-    ro, to = orc.trace(1920, 1080, ijs, 50, 1, accel=oracle.ACCEL_BVH)
+    ro, to = orc.trace(1920, 1080, ijs, 50, 1, accel=oracle.ACCEL_PADDED_LIST)
     assert_same(rg, ro, "C4 per-sample radiance")
     assert np.array_equal(tg, to)
     out = (C.c_uint8 * 3)()
     for i, j in ((0, 0), (1919, 1079), (960, 700), (400, 900), (1500, 650), (777, 555)):
         pij = np.array([[i, j, s] for s in range(1, 513)], dtype=np.uint32)
-        rgb, _ = orc.trace(1920, 1080, pij, 50, 1, accel=oracle.ACCEL_BVH)
+        rgb, _ = orc.trace(1920, 1080, pij, 50, 1, accel=oracle.ACCEL_PADDED_LIST)
         acc = np.zeros(3, dtype=np.float32)
         for s in range(512):
             acc = acc + rgb[s]
@@ -737,7 +750,7 @@ def test_sampler_variants_device_vs_oracle(hip, oracle, scenes_mod, flags):
         sg = hip.render(W, H, 1, 4, 50, 1)
         hip.resolve()
         hg, lg = hip.download()
-        so = orc.render(W, H, 1, 4, 50, 1, accel=oracle.ACCEL_BVH, threads=8)
+        so = orc.render(W, H, 1, 4, 50, 1, accel=oracle.ACCEL_PADDED_LIST, threads=8)
         orc.resolve()
         ho, lo = orc.download()
         assert_same(hg, ho, "HDR, sampler %d" % flags)
@@ -768,7 +781,7 @@ def test_gpu_image_agrees_with_the_reference_halton_counter_estimator(hip, oracl
         oracle.lib().orc_use_reference_halton_counters(1)
         orc = oracle.Oracle()
         orc.upload(sc)  # fresh materials: counters start at 0 like a fresh process
-        orc.render(W, H, 1, 1 + spp, 50, 1, accel=oracle.ACCEL_BVH, threads=1)
+        orc.render(W, H, 1, 1 + spp, 50, 1, accel=oracle.ACCEL_PADDED_LIST, threads=1)
         ref, _ = orc.download()
     finally:
         oracle.lib().orc_use_reference_halton_counters(0)
@@ -911,7 +924,7 @@ def test_c5_full_size_properties(hip, oracle, scenes_mod):
     out = (C.c_uint8 * 3)()
     for i, j in ((0, 0), (4095, 4095), (2048, 2600), (1000, 3000), (3100, 2200), (2047, 1900)):
         pij = np.array([[i, j, s] for s in range(1, 65)], dtype=np.uint32)
-        rgb, _ = orc.trace(W, H, pij, 50, 1, accel=oracle.ACCEL_BVH)
+        rgb, _ = orc.trace(W, H, pij, 50, 1, accel=oracle.ACCEL_PADDED_LIST)
         acc = np.zeros(3, dtype=np.float32)
         for s in range(64):
             acc = acc + rgb[s]

@@ -385,6 +385,93 @@ def test_bvh_equals_list_on_random_rays_and_images(oracle):
 
 
 # ------------------------------------------------------------------------ render loop
+def test_exact_tie_goes_to_the_lower_list_index(oracle):
+    """Found by the full-size differential of config C4 (sample (1226, 751, 386), third segment): a ray that meets spheres
+    427 and 428 of the cover scene -- two overlapping small spheres -- at the SAME binary32 t.  The reference's BvhNode gives
+    an exact tie to the right child of a tree built on unseeded std::rand() axes (ray-tracing.cpp:121,184-191), so the
+    reference itself does not reproduce it; the path's contract is the list scan's rule, lower list index (SURVEY.md §8a
+    A6), and the oracle's BvhNode follows it.  The reference's rule stays selectable and picks the other sphere here."""
+    sc = oracle.build_scene("cover", 1, 1.5)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    ray = np.array([[5.776693344116211, -0.016715288162231445, 0.024381153285503387,
+                     0.7938283681869507, 0.058303073048591614, -0.6053406596183777]], dtype=np.float32)
+    hl = orc.closest_hit(ray, oracle.ACCEL_LIST)
+    hb = orc.closest_hit(ray, oracle.ACCEL_BVH)
+    assert int(hl[0, 1:2].view(np.int32)[0]) == 427 and np.array_equal(hl.view(np.uint32), hb.view(np.uint32))
+    oracle.lib().orc_use_reference_bvh_tie_rule(1)
+    try:
+        hr = orc.closest_hit(ray, oracle.ACCEL_BVH)
+    finally:
+        oracle.lib().orc_use_reference_bvh_tie_rule(0)
+    assert int(hr[0, 1:2].view(np.int32)[0]) == 428
+    assert hr[0, 0:1].view(np.uint32)[0] == hl[0, 0:1].view(np.uint32)[0]  # the same t, bit for bit
+    assert np.array_equal(hr[0, 2:5].view(np.uint32), hl[0, 2:5].view(np.uint32))  # hence the same position; the normals differ
+    assert not np.array_equal(hr[0, 5:8], hl[0, 5:8])
+
+
+def _grazing_rays(sc, rng, n):
+    """Rays aimed at the silhouettes of random spheres from 2 to 150 scene units away, missing or cutting them by 1e-7 .. 1e-2
+    of the radius: where a binary32 discriminant and a box test disagree."""
+    c = np.stack([sc.spheres["cx"], sc.spheres["cy"], sc.spheres["cz"]], 1).astype(np.float64)
+    r = sc.spheres["r"].astype(np.float64)
+    k = rng.integers(0, len(r), n)
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    o = c[k] + u * (r[k] + np.exp(rng.uniform(np.log(2.0), np.log(150.0), n)))[:, None]
+    w = np.cross(u, rng.normal(size=(n, 3)))
+    w /= np.linalg.norm(w, axis=1, keepdims=True)
+    off = r[k] * (1.0 + rng.choice([-1.0, 1.0], n) * np.exp(rng.uniform(np.log(1e-7), np.log(1e-2), n)))
+    d = (c[k] + w * off[:, None]) - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([o, d], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("name,n_random,n_grazing", [("cover", 60000, 60000), ("grid10k", 6000, 14000)])
+def test_padded_list_tree_is_the_list_scan(oracle, name, n_random, n_grazing):
+    """ACCEL_PADDED_LIST (what the full-size digests are made with) returns the plain list scan's hit record, bit for bit, on
+    random rays and on rays grazing sphere silhouettes -- and on those the reference's BvhNode does NOT always (its binary32
+    slab test loses hits the list finds): the reason the contract is the list."""
+    from concurrent.futures import ThreadPoolExecutor
+    sc = oracle.build_scene(name, 1, 1.0)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    rng = np.random.default_rng(77)
+    o = rng.uniform(-60, 60, (n_random, 3)) * [1, 0.1, 1] + [0, 2, 0]
+    d = rng.normal(size=(n_random, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([np.concatenate([o, d], 1).astype(np.float32), _grazing_rays(sc, rng, n_grazing)])
+    chunks = np.array_split(np.arange(len(rays)), 32)
+    with ThreadPoolExecutor(8) as ex:
+        hl = np.concatenate(list(ex.map(lambda ix: orc.closest_hit(rays[ix], oracle.ACCEL_LIST), chunks)))
+        hp = np.concatenate(list(ex.map(lambda ix: orc.closest_hit(rays[ix], oracle.ACCEL_PADDED_LIST), chunks)))
+        hb = np.concatenate(list(ex.map(lambda ix: orc.closest_hit(rays[ix], oracle.ACCEL_BVH), chunks)))
+    assert np.array_equal(hl.view(np.uint32), hp.view(np.uint32))
+    assert (hl[:, 1].view(np.int32) >= 0).sum() > len(rays) // 4
+    lost = int(((hl[:, 1].view(np.int32) >= 0) & (hb[:, 1].view(np.int32) != hl[:, 1].view(np.int32))).sum())
+    print("%s: BvhNode differs from the list on %d of %d rays" % (name, lost, len(rays)))
+
+
+def test_known_paths_where_the_reference_bvh_is_not_the_list(oracle):
+    """The samples on which round 3's full-size differentials first disagreed (oracle BvhNode vs GPU): the GPU had the list's
+    answer every time.  C4: the exact tie above.  C5 (grid10k, 4096^2): grazing hits BvhNode's slab test rejects."""
+    for name, aspect, ap, W, H, samples in (("cover", 1920 / 1080.0, 2.0, 1920, 1080, [(1226, 751, 386)]),
+                                            ("grid10k", 1.0, -1.0, 4096, 4096, [(1837, 1377, 48), (2326, 1410, 64), (2295, 1465, 59), (2265, 1472, 19)])):
+        sc = oracle.build_scene(name, 1, aspect, ap)
+        orc = oracle.Oracle()
+        orc.upload(sc)
+        ijs = np.array(samples, dtype=np.uint32)
+        rl, tl = orc.trace(W, H, ijs, 50, 1, accel=oracle.ACCEL_LIST)
+        rp, tp = orc.trace(W, H, ijs, 50, 1, accel=oracle.ACCEL_PADDED_LIST)
+        assert np.array_equal(rl.view(np.uint32), rp.view(np.uint32)) and np.array_equal(tl, tp)
+        oracle.lib().orc_use_reference_bvh_tie_rule(1)
+        try:
+            rb, tb = orc.trace(W, H, ijs, 50, 1, accel=oracle.ACCEL_BVH)
+        finally:
+            oracle.lib().orc_use_reference_bvh_tie_rule(0)
+        assert (tb != tl).all()  # every one of them differs under the reference's accelerator
+
+
 def test_c1_matches_committed_golden(oracle):
     g = np.load(os.path.join(GOLDEN, "c1_three_200x100_spp1_d8.npz"))
     sc = oracle.build_scene("three", 1, 2.0)

@@ -61,7 +61,22 @@ wc = t["SQ_WAVE_CYCLES"]
 derived["wave_time_split"] = {"issuing": t["SQ_ACTIVE_INST_ANY"] / wc, "wait_inst_issue": t["SQ_WAIT_INST_ANY"] / wc, "wait_cnt_or_barrier": t["SQ_WAIT_ANY"] / wc}
 if "SQ_LDS_BANK_CONFLICT" in t and t.get("SQ_LDS_IDX_ACTIVE"):
     derived["lds_bank_conflict_frac"] = t["SQ_LDS_BANK_CONFLICT"] / t["SQ_LDS_IDX_ACTIVE"]
-out = {"kernel_sources_sha256": _bench.kernel_sources_hash(),
+# the hash of the kernel sources comes from the RUNS that were profiled (every bench line prints roofline.kernel_sources_sha256),
+# never from the working tree at summary time: an edit between profile_round.sh and this script must not restamp old counters
+run_hashes = {}
+for f in ["bench.json", "bench_kt.json"] + sorted(os.path.basename(x) for x in glob.glob(os.path.join(src, "pmc_*.json"))):
+    ln = last_json_line(os.path.join(src, f))
+    assert ln is not None, "no bench line in " + f
+    run_hashes[f] = ln["roofline"]["kernel_sources_sha256"]
+    assert ln["n_gpus"] == 1 and ln["config"]["name"] == bench["config"]["name"], f + " profiled another workload"
+assert len(set(run_hashes.values())) == 1, "the passes of this profile ran different kernel builds: %s" % run_hashes
+profiled_hash = run_hashes["bench.json"]
+if profiled_hash != _bench.kernel_sources_hash():
+    print("summarize_profile.py: NOTE: the working tree's kernel sources differ from the profiled build (%s...): the summary keeps "
+          "the profiled hash and bench.py will withhold the roofline until the profile is redone" % profiled_hash[:12], file=sys.stderr)
+_cfg = _bench.CONFIGS[bench["config"]["name"]]
+out = {"kernel_sources_sha256": profiled_hash,
+       "workload_key": {"n_gpus": bench["n_gpus"], "W": _cfg["W"], "H": _cfg["H"], "spp": bench["config"]["spp"], "config": bench["config"]["name"]},
        "command": "tools/profile_round.sh: rocprofv3 --kernel-trace --stats (durations) and four separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ group | SQ+MFMA+GRBM group) over python3 bench.py; summarised by tools/summarize_profile.py",
        "workload": bench["config"]["workload"], "kernel": trace_name, "raw_counters": raw, "derived_trace_kernel": derived}
 prev = prefix + "_pmc_summary" + suffix + ".json"
