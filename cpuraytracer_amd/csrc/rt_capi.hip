@@ -86,6 +86,7 @@ struct rt_ctx {
     DevBuf<float4> scan, tree, leaf;
     DevBuf<uint32_t> orig;
     DevBuf<uint16_t> sgCells, sgEntries, sgGlobal;
+    DevBuf<uint16_t> gridCells;  // cell-grid scan: first scan entry per cell
     bool useShadowGrid = true;  // RT_SHADOW_GRID=0 keeps every shadow ray on the scan
     DevBuf<float> radius;
     DevBuf<rt_material> mats;
@@ -168,6 +169,11 @@ struct SceneLayout {
     uint32_t nAlways = 0;         // hierarchy scan: leading big-sphere groups kept out of the hierarchy (tested for every ray)
     float treeBox[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // box around the spheres in the hierarchy (lo, hi, max |coordinate|)
     bool treeBoxOn = false;
+    // cell-grid scan (rt_scan.h scan_list_grid): the small spheres sorted by home cell behind the big ones
+    bool gridOn = false;
+    std::vector<uint16_t> gridCellStart;  // [nu * nv + 1]
+    uint32_t gridNu = 0, gridNv = 0, gridAxU = 0, gridAxV = 2;
+    float gridG0u = 0.f, gridG0v = 0.f, gridInvH = 0.f, gridRmaxOverH = 0.f;
 };
 
 // Conservative bounding sphere of a set of spheres, in the filter's (C, |C|^2 - Rf^2) form.
@@ -328,6 +334,118 @@ static void RefineGroups(const rt_sphere* sp, std::vector<std::vector<uint32_t>>
     }
 }
 
+// Box around a set of spheres (radii included) and the constants of the per-ray padding (rt_scan.h): treeBox[0..5] = lo, hi,
+// [6] = max |coordinate|, [7] = 3 A^2 (A = max |c| + r), [8] = 1 / (2 r_min).
+static bool BoxOf(const rt_sphere* sp, const std::vector<uint32_t>& ids, float treeBox[9]) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    double A = 0.0, rmin = 1e300;
+    for (uint32_t k : ids) {
+        const double c[3] = {sp[k].cx, sp[k].cy, sp[k].cz};
+        A = std::max(A, std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + (double)sp[k].r);
+        rmin = std::min(rmin, (double)sp[k].r);
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], c[a] - (double)sp[k].r * (1.0 + 1e-5));
+            hi[a] = std::max(hi[a], c[a] + (double)sp[k].r * (1.0 + 1e-5));
+        }
+    }
+    if (!(lo[0] <= hi[0])) return false;
+    double am = 0;
+    for (int a = 0; a < 3; ++a) {
+        treeBox[a] = std::nextafterf((float)lo[a], -INFINITY);
+        treeBox[3 + a] = std::nextafterf((float)hi[a], INFINITY);
+        am = std::max(am, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
+    }
+    treeBox[6] = (float)(am * 1.001);
+    treeBox[7] = (float)(3.0 * A * A * 1.001);
+    treeBox[8] = (float)(1.001 / (2.0 * rmin));
+    return true;
+}
+
+// Cell-grid layout (rt_scan.h scan_list_grid) for a scene of at most eight big spheres and a layer of many small ones: the big
+// spheres keep the leading one-sphere groups (entries 4q; every ray tests them exactly), the small spheres follow SORTED BY
+// HOME CELL of a uniform grid over the two long axes of their box -- cell = iu * nv + iv, so a run of cells of one u-slab is a
+// run of scan entries -- about 1.5 spheres per cell, at most 254 x 254 cells.  false: the scene does not suit (the caller builds
+// the bounds hierarchy instead).
+static bool BuildGridLayout(const rt_sphere* sp, uint32_t n, const std::vector<uint32_t>& big, const std::vector<uint32_t>& small, SceneLayout& L) {
+    if (big.size() > 8 || small.size() < 512) return false;
+    if (!BoxOf(sp, small, L.treeBox)) return false;
+    const double ext[3] = {(double)L.treeBox[3] - L.treeBox[0], (double)L.treeBox[4] - L.treeBox[1], (double)L.treeBox[5] - L.treeBox[2]};
+    int w = 0;
+    if (ext[1] < ext[w]) w = 1;
+    if (ext[2] < ext[w]) w = 2;
+    const int axU = (w + 1) % 3, axV = (w + 2) % 3;
+    double rmax = 0;
+    for (uint32_t k : small) rmax = std::max(rmax, (double)sp[k].r);
+    double h = std::sqrt(std::max(ext[axU] * ext[axV], 1e-30) * 1.5 / (double)small.size());
+    h = std::max(h, 2.5 * rmax);                                  // a sphere's neighbourhood stays within one cell of its home
+    h = std::max(h, std::max(ext[axU], ext[axV]) / 250.0);         // at most 254 cells per axis
+    const float g0u = L.treeBox[axU] - (float)(0.01 * h), g0v = L.treeBox[axV] - (float)(0.01 * h);
+    const float invH = (float)(1.0 / h);
+    const uint32_t nu = (uint32_t)std::floor(((double)L.treeBox[3 + axU] - g0u) * invH) + 2u;
+    const uint32_t nv = (uint32_t)std::floor(((double)L.treeBox[3 + axV] - g0v) * invH) + 2u;
+    if (nu > 254u || nv > 254u || (size_t)nu * nv > 60000u) return false;
+    auto coord = [&](uint32_t k, int ax) { return ax == 0 ? sp[k].cx : (ax == 1 ? sp[k].cy : sp[k].cz); };
+    std::vector<std::pair<uint32_t, uint32_t>> keyed;  // (home cell, sphere)
+    keyed.reserve(small.size());
+    for (uint32_t k : small) {
+        // the device forms (x - g0) * invH in float; the host's double value differs by < 1e-4 cells, inside the walk's slack
+        const double fu = ((double)coord(k, axU) - (double)g0u) * (double)invH, fv = ((double)coord(k, axV) - (double)g0v) * (double)invH;
+        const uint32_t iu = (uint32_t)std::min(std::max(std::floor(fu), 0.0), (double)(nu - 1u));
+        const uint32_t iv = (uint32_t)std::min(std::max(std::floor(fv), 0.0), (double)(nv - 1u));
+        keyed.push_back({iu * nv + iv, k});
+    }
+    std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
+    std::vector<std::vector<uint32_t>> groups;
+    for (uint32_t k : big) groups.push_back({k});
+    while (groups.size() & 3u) groups.push_back({});
+    const uint32_t base = (uint32_t)groups.size() * 4u;  // first entry of the sorted small spheres
+    for (size_t q = 0; q < keyed.size(); q += 4) {
+        std::vector<uint32_t> g;
+        for (size_t m = q; m < std::min(q + 4, keyed.size()); ++m) g.push_back(keyed[m].second);
+        groups.push_back(g);
+    }
+    while (groups.size() & 3u) groups.push_back({});
+    if (groups.size() * 4 + 4 >= 65536) return false;
+    L.nGroups = (uint32_t)groups.size();
+    const float4 never = make_float4(0.f, 0.f, 0.f, -1e30f);
+    L.scan.assign((size_t)L.nGroups * 4 + 4, never);
+    L.orig.assign((size_t)L.nGroups * 4 + 4, 0xffffffffu);
+    for (uint32_t gi = 0; gi < L.nGroups; ++gi)
+        for (size_t m = 0; m < groups[gi].size(); ++m) {
+            const uint32_t k = groups[gi][m];
+            L.scan[(size_t)gi * 4 + m] = make_float4(sp[k].cx, sp[k].cy, sp[k].cz, sp[k].r * sp[k].r);
+            L.orig[(size_t)gi * 4 + m] = k;
+        }
+    L.gridCellStart.assign((size_t)nu * nv + 1, 0);
+    {
+        size_t q = 0;
+        for (uint32_t c = 0; c <= nu * nv; ++c) {
+            while (q < keyed.size() && keyed[q].first < c) ++q;
+            L.gridCellStart[c] = (uint16_t)(base + q);
+        }
+    }
+    L.singleMask[0] = L.singleMask[1] = 0ull;
+    L.leaf.assign(L.scan.size(), BoundOf(sp, {}, nullptr, rtd::kMarginKLeaf));
+    L.boundNorm = 0.f;
+    for (size_t e = 0; e < L.orig.size(); ++e)
+        if (L.orig[e] != 0xffffffffu) L.leaf[e] = BoundOf(sp, {L.orig[e]}, e >= base ? &L.boundNorm : nullptr, rtd::kMarginKLeaf);
+    L.nAlways = (uint32_t)big.size();
+    // one level of group bounds for rt_unit_layout's readers (the scan does not use them); the big spheres' groups are out of it
+    L.tree.clear();
+    L.nLevels = 1;
+    L.levelOff[0] = 0;
+    L.levelCnt[0] = L.nGroups;
+    for (uint32_t gi = 0; gi < L.nGroups; ++gi) {
+        float norm = 0.f;
+        L.tree.push_back(gi < L.nAlways ? BoundOf(sp, {}, nullptr, rtd::kMarginKValu) : BoundOf(sp, groups[gi], &norm, rtd::kMarginKValu));
+    }
+    L.treeBoxOn = true;
+    L.gridOn = true;
+    L.gridNu = nu; L.gridNv = nv; L.gridAxU = (uint32_t)axU; L.gridAxV = (uint32_t)axV;
+    L.gridG0u = g0u; L.gridG0v = g0v; L.gridInvH = invH; L.gridRmaxOverH = (float)(rmax * (double)invH * 1.0001);
+    return true;
+}
+
 static void BuildLayout(const rt_sphere* sp, uint32_t n, uint32_t topMax, SceneLayout& L) {
     std::vector<float> radii(n);
     for (uint32_t k = 0; k < n; ++k) radii[k] = sp[k].r;
@@ -336,6 +454,14 @@ static void BuildLayout(const rt_sphere* sp, uint32_t n, uint32_t topMax, SceneL
     const float median = sorted[n / 2];
     std::vector<uint32_t> big, small;
     for (uint32_t k = 0; k < n; ++k) (radii[k] > 4.f * median ? big : small).push_back(k);
+    // scenes beyond the flat matrix-core filter (more than topMax groups of four): a cell grid over the layer of small spheres
+    // when the scene suits it (RT_GRID=0: always the bounds hierarchy)
+    {
+        const char* g = std::getenv("RT_GRID");
+        const bool wantGrid = !(g && g[0] == '0') && std::getenv("RT_ALWAYS_BIG") == nullptr;
+        if (wantGrid && (small.size() + 3) / 4 + big.size() > topMax && BuildGridLayout(sp, n, big, small, L)) return;
+        L = SceneLayout{};
+    }
     // k-d median split down to leaves of four, emitted in tree order: compact, balanced groups whose
     // neighbours in the list are neighbours in space (Morton chunks of a jittered grid have 3x the summed R^2
     // and twice the filter candidates; tools/cluster_eval.py)
@@ -425,30 +551,9 @@ static void BuildLayout(const rt_sphere* sp, uint32_t n, uint32_t topMax, SceneL
     }
     L.treeBoxOn = false;
     if (levels.size() > 1 && std::getenv("RT_TREE_BOX_OFF") == nullptr) {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        double A = 0.0, rmin = 1e300;
-        for (const auto& ids : levels[0])
-            for (uint32_t k : ids) {
-                const double c[3] = {sp[k].cx, sp[k].cy, sp[k].cz};
-                A = std::max(A, std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + (double)sp[k].r);
-                rmin = std::min(rmin, (double)sp[k].r);
-                for (int a = 0; a < 3; ++a) {
-                    lo[a] = std::min(lo[a], c[a] - (double)sp[k].r * (1.0 + 1e-5));
-                    hi[a] = std::max(hi[a], c[a] + (double)sp[k].r * (1.0 + 1e-5));
-                }
-            }
-        if (lo[0] <= hi[0]) {
-            double am = 0;
-            for (int a = 0; a < 3; ++a) {
-                L.treeBox[a] = std::nextafterf((float)lo[a], -INFINITY);
-                L.treeBox[3 + a] = std::nextafterf((float)hi[a], INFINITY);
-                am = std::max(am, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
-            }
-            L.treeBox[6] = (float)(am * 1.001);
-            L.treeBox[7] = (float)(3.0 * A * A * 1.001);
-            L.treeBox[8] = (float)(1.001 / (2.0 * rmin));
-            L.treeBoxOn = true;
-        }
+        std::vector<uint32_t> inTree;
+        for (const auto& ids : levels[0]) inTree.insert(inTree.end(), ids.begin(), ids.end());
+        L.treeBoxOn = BoxOf(sp, inTree, L.treeBox);
     }
     L.tree.clear();
     L.nLevels = (uint32_t)levels.size();
@@ -587,7 +692,7 @@ static size_t MfmaOpsBytesFor(uint32_t nGroups) { return (size_t)rtd::mfma_tiles
 // entry, so that it runs the scan rt_render runs): tree = hierarchy scan <false, ., 2>, flat = matrix-core filter over the
 // groups with every table in LDS <true, ., 1>, else the VALU scan with (ldsTables) or without LDS tables.
 struct TraceVariant {
-    bool tree, flat, ldsTables;
+    bool tree, flat, ldsTables, grid;
     size_t candBytes, leafBytes;
 };
 static TraceVariant ChooseVariant(const rt_ctx* ctx, const rtd::TraceParams& tp) {
@@ -595,13 +700,14 @@ static TraceVariant ChooseVariant(const rt_ctx* ctx, const rtd::TraceParams& tp)
     const size_t lds = LdsBytesFor(tp.n, tp.n_padded, ctx->matsInLds);
     const bool useLds = !ctx->forceGlobal && lds <= 48 * 1024 && tp.n_padded < 65536;
     const uint32_t wavesPerBlock = ctx->blockThreads / 64;
-    V.tree = ctx->useMfma && tp.n_levels > 1;  // deeper hierarchy: tables stay in global memory (L2)
+    V.grid = ctx->useMfma && tp.grid_cell_start != nullptr;  // cell-grid scan (the scene was laid out for it at upload): tables in global memory (L2)
+    V.tree = ctx->useMfma && !V.grid && tp.n_levels > 1;  // deeper hierarchy: tables stay in global memory (L2)
     const uint32_t topCnt = tp.level_cnt[tp.n_levels - 1];
     // the scene constants' slot comes first in the image, then the per-wave regions
-    V.candBytes = rtd::kConstBytes + (size_t)wavesPerBlock * (V.tree ? rtd::kWaveCandBytes : rtd::kWaveListBytes);
+    V.candBytes = rtd::kConstBytes + (size_t)wavesPerBlock * ((V.tree || V.grid) ? rtd::kWaveCandBytes : rtd::kWaveListBytes);
     V.leafBytes = (size_t)tp.n_padded * 16;  // one-sphere bounds, staged next to the scan table by the flat scan
-    V.flat = !V.tree && useLds && ctx->useMfma && (V.candBytes + lds + V.leafBytes + MfmaOpsBytesFor(topCnt)) <= 160 * 1024;
-    V.ldsTables = useLds && !V.tree;
+    V.flat = !V.tree && !V.grid && useLds && ctx->useMfma && (V.candBytes + lds + V.leafBytes + MfmaOpsBytesFor(topCnt)) <= 160 * 1024;
+    V.ldsTables = useLds && !V.tree && !V.grid;
     return V;
 }
 
@@ -672,7 +778,12 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     size_t treeBytes = tree ? (size_t)(tp.level_off[tp.n_levels - 1] + topCnt) * 16 : 0;
     if (!ctx->treeInLds || candBytes + MfmaOpsBytesFor(topCnt) + treeBytes > 160 * 1024) treeBytes = 0;
     tp.tree_in_lds = treeBytes ? 1u : 0u;
-    size_t ldsBytes = candBytes + (ldsTables ? lds : 0) + (flat ? leafBytes : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0) + sgBytes + treeBytes;
+    const bool grid = V.grid;
+    // (the cells go to LDS in the 1024-thread variants; smaller workgroups -- a knob for experiments -- read them through L2)
+    size_t gridBytes = (grid && ctx->blockThreads == 1024) ? (((size_t)tp.grid_nu * tp.grid_nv + 1) * 2 + 15) / 16 * 16 : 0;
+    if (candBytes + gridBytes > 160 * 1024) gridBytes = 0;  // (cannot happen below 60,000 cells)
+    tp.grid_in_lds = gridBytes ? 1u : 0u;
+    size_t ldsBytes = candBytes + (ldsTables ? lds : 0) + (flat ? leafBytes : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0) + sgBytes + treeBytes + gridBytes;
     // per-wave caches of prepared paths go last, when there is room left (RT_RAY_CACHE=0 disables them)
     ldsBytes = (ldsBytes + 15) / 16 * 16;
     tp.ray_cache_off16 = 0;
@@ -688,7 +799,7 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
         cap = cap > 63u ? 63u : cap;
         const uint32_t capEnv = EnvU32("RT_STASH_CAP", 63u);
         cap = cap > capEnv ? capEnv : cap;
-        if (ctx->useStash && carryMode == 0 && (flat || tree) && ctx->blockThreads == 1024 && tp.max_depth < 65536u && cap >= 16u) {
+        if (ctx->useStash && carryMode == 0 && (flat || tree || grid) && ctx->blockThreads == 1024 && tp.max_depth < 65536u && cap >= 16u) {
             useStash = true;
             tp.stash_cap = cap;
             tp.ray_cache_off16 = (uint32_t)(ldsBytes / 16);
@@ -736,6 +847,14 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
         else RT_LAUNCH(LDS, 256, M);                                   \
     } while (0)
     if (carryMode == 2) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 1, true, true, true>));
+    else if (grid && ctx->blockThreads == 1024 && useStash && tp.grid_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 3, true, true, false, true>));
+    else if (grid && ctx->blockThreads == 1024 && tp.grid_in_lds && tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 3, true, true>));
+    else if (grid && ctx->blockThreads == 1024 && tp.grid_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 3, false, true>));
+    else if (grid && ctx->blockThreads == 1024) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 3, false, false>));
+    else if (grid && ctx->blockThreads == 512 && !tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 512, 3, false, false>));
+    else if (grid && ctx->blockThreads == 512) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 512, 3, true, false>));
+    else if (grid && !tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 256, 3, false, false>));
+    else if (grid) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 256, 3, true, false>));
     else if (useStash && tree && tp.tree_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 2, true, true, false, true>));
     else if (useStash && tree) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 2, true, false, false, true>));
     else if (useStash && hitLds) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 1, true, true, false, true>));
@@ -762,8 +881,10 @@ static int LaunchClosest(rt_ctx* ctx, const float* dRays, uint32_t n, float* dOu
         tp.sg_in_lds = 0;
         const uint32_t topCnt = tp.level_cnt[tp.n_levels - 1];
         const size_t waves = 256 / 64;
-        size_t ldsBytes = waves * (V.tree ? rtd::kWaveCandBytes : rtd::kWaveListBytes);
-        if (V.tree) {
+        size_t ldsBytes = waves * ((V.tree || V.grid) ? rtd::kWaveCandBytes : rtd::kWaveListBytes);
+        if (V.grid) {
+            tp.grid_in_lds = 0;
+        } else if (V.tree) {
             ldsBytes += MfmaOpsBytesFor(topCnt);
             const size_t treeBytes = (size_t)(tp.level_off[tp.n_levels - 1] + topCnt) * 16;
             tp.tree_in_lds = (ctx->treeInLds && ldsBytes + treeBytes <= 160 * 1024) ? 1u : 0u;
@@ -778,7 +899,8 @@ static int LaunchClosest(rt_ctx* ctx, const float* dRays, uint32_t n, float* dOu
         if (ldsBytes > 48 * 1024) RT_HIP(hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
         hipLaunchKernelGGL((rtd::k_unit_closest<LDS, M>), dim3((n + 255) / 256), dim3(256), ldsBytes, ctx->stream, tp, dRays, n, dOut); \
     } while (0)
-        if (V.tree) RT_UNIT_CLOSEST(false, 2);
+        if (V.grid) RT_UNIT_CLOSEST(false, 3);
+        else if (V.tree) RT_UNIT_CLOSEST(false, 2);
         else if (V.flat) RT_UNIT_CLOSEST(true, 1);
         else if (V.ldsTables) RT_UNIT_CLOSEST(true, 0);
         else RT_UNIT_CLOSEST(false, 0);
@@ -1040,6 +1162,7 @@ void rt_destroy(rt_ctx* ctx) {
     ctx->orig.Release();
     ctx->tree.Release();
     ctx->sgCells.Release();
+    ctx->gridCells.Release();
     ctx->sgEntries.Release();
     ctx->sgGlobal.Release();
     ctx->radius.Release();
@@ -1141,8 +1264,24 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
         if (!SG.global.empty()) RT_HIP(hipMemcpy(ctx->sgGlobal.ptr, SG.global.data(), SG.global.size() * 2, hipMemcpyHostToDevice));
     }
 
+    if (L.gridOn) {
+        if ((rc = ctx->gridCells.Reserve(L.gridCellStart.size())) != RT_OK) return rc;
+        RT_HIP(hipMemcpy(ctx->gridCells.ptr, L.gridCellStart.data(), L.gridCellStart.size() * 2, hipMemcpyHostToDevice));
+    }
+
     rtd::TraceParams& b = ctx->base;
     b = rtd::TraceParams{};
+    if (L.gridOn) {
+        b.grid_cell_start = ctx->gridCells.ptr;
+        b.grid_nu = L.gridNu;
+        b.grid_nv = L.gridNv;
+        b.grid_ax_u = L.gridAxU;
+        b.grid_ax_v = L.gridAxV;
+        b.grid_g0u = L.gridG0u;
+        b.grid_g0v = L.gridG0v;
+        b.grid_inv_h = L.gridInvH;
+        b.grid_rmax_over_h = L.gridRmaxOverH;
+    }
     b.sg_enabled = SG.enabled ? 1u : 0u;
     if (SG.enabled) {
         b.sg_cell_start = ctx->sgCells.ptr;

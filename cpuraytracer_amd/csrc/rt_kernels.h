@@ -97,6 +97,7 @@ struct SceneTabs {
     const float* ops;       // filter operand image of the top level (matrix-core scans)
     const float4* tree;
     const uint16_t *sgCell, *sgEntries, *sgGlobal;
+    const uint16_t* gridCells;  // cell-grid scan: first scan entry per cell
     uint32_t nTop, nTiles;
 };
 
@@ -110,7 +111,8 @@ struct SceneTabs {
 // for the previous iteration's sample stores.  The host launches it only when p.mats_in_lds and (p.sg_in_lds or no index).
 template <bool kLds, int kScan, bool kHitLds = false>
 RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
-    constexpr bool kMfma = kScan != 0;
+    constexpr bool kMfma = kScan == 1 || kScan == 2;
+    T.gridCells = p.grid_cell_start;
     T.scan = p.scan;
     T.orig = p.orig;
     T.leaf = p.leaf;
@@ -175,6 +177,15 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
         T.rad = ldsRad;
         if (kHitLds) T.mats = reinterpret_cast<const rt_material*>(ldsMat);
         else if (p.mats_in_lds) T.mats = reinterpret_cast<const rt_material*>(ldsMat);
+    } else if (kScan == 3) {
+        // cell-grid scan: the exact tables stay in global memory (L2); the cells' first entries live in LDS (kHitLds: typed pointer)
+        if (kHitLds) {
+            uint16_t* g = reinterpret_cast<uint16_t*>(tabBase);
+            const uint32_t nc = p.grid_nu * p.grid_nv + 1u;
+            for (uint32_t k = threadIdx.x; k < nc; k += blockDim.x) g[k] = p.grid_cell_start[k];
+            T.gridCells = g;
+            __syncthreads();
+        }
     } else if (kMfma) {
         // exact tables stay in global memory (L2); the top level's operand image and, when they fit, all bounds live in LDS
         float* ldsOps = reinterpret_cast<float*>(tabBase);
@@ -250,10 +261,10 @@ RT_DEV bool claim_block(const TraceParams& p, SceneConsts* ldsK, uint32_t lane, 
 // operations on the same values as before: only WHEN a hit is processed changes, never what is computed.
 template <bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds = false, bool kCarry = false, bool kStash = false>
 __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams p) {
-    constexpr bool kMfma = kScan != 0;
+    constexpr bool kMfma = kScan == 1 || kScan == 2;  // matrix-core filter; kScan == 3: cell-grid scan (rt_scan.h scan_list_grid)
     static_assert(!kCarry || (kCache && kHitLds && kScan == 1), "frame pipelining is built for the flat LDS variant only");
     static_assert(!kStash || (kCache && !kCarry), "the hit stash takes the LDS region of the prepared-path cache");
-    static_assert(!kHitLds || kScan != 0, "kHitLds belongs to the matrix-core variants");
+    static_assert(!kHitLds || kScan != 0, "kHitLds belongs to the matrix-core and grid variants");
 #ifdef RT_TIMELINE
     const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz; diagnostic build only
     uint32_t tlCarriedIn = 0;
@@ -275,7 +286,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     const MathTabs mt{ldsMath, ldsMath + 94, ldsMath + 127};
 #endif
     uint16_t* candBase = reinterpret_cast<uint16_t*>(smem + kConstBytes / 16);
-    constexpr uint32_t kWaveRegion = kScan == 2 ? kWaveCandBytes : kWaveListBytes;  // the descent stack only exists in tree mode
+    constexpr uint32_t kWaveRegion = kScan >= 2 ? kWaveCandBytes : kWaveListBytes;  // the work lists of the hierarchy and grid scans
     float4* tabBase = smem + kConstBytes / 16 + (kThreads / kWaveSize) * (kWaveRegion / 16);
     SceneTabs T;
     stage_scene<kLds, kScan, kHitLds>(p, tabBase, T);  // ends with a workgroup barrier when it staged anything
@@ -289,6 +300,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     const uint16_t* sgCell = T.sgCell;
     const uint16_t* sgEntries = T.sgEntries;
     const uint16_t* sgGlobal = T.sgGlobal;
+    const uint16_t* gridCells = T.gridCells;
     const uint32_t nTop = T.nTop, nTiles = T.nTiles;
 
     const uint32_t lane = threadIdx.x & (kWaveSize - 1);
@@ -715,6 +727,9 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
             // the ray owned by lane l^32, whether or not its own ray is live
             scan_list_mfma<kScan == 2>(scanTab, leafTab, origTab, mfmaOps, nTiles, nTop, treeTab, p.level_off, p.n_levels, p.bound_norm, p.single_mask, p.n_always, p.tree_box_on ? p.tree_box : nullptr, ro, rd,
                                        live, tmin, idx, waveCand, lane, dbgScan);
+        } else if (kScan == 3) {
+            const GridParams G{gridCells, p.grid_nu, p.grid_nv, p.grid_ax_u, p.grid_ax_v, p.grid_g0u, p.grid_g0v, p.grid_inv_h, p.grid_rmax_over_h};
+            scan_list_grid(scanTab, leafTab, origTab, G, gridCells, p.n_always, p.tree_box, p.bound_norm, ro, rd, live, tmin, idx, waveCand, lane);
         } else if (live) {
             scan_list_deferred(scanTab, origTab, p.n_padded, ro, rd, tmin, idx, cand);
         }
@@ -1087,7 +1102,7 @@ __global__ void k_unit_primary(const TraceParams p, const uint32_t* ijs, uint32_
 template <bool kLds, int kScan>
 __global__ void __launch_bounds__(256) k_unit_closest(const TraceParams p, const float* rays, uint32_t n, float* out) {
     extern __shared__ float4 smem[];
-    constexpr uint32_t kWaveRegion = kScan == 2 ? kWaveCandBytes : kWaveListBytes;
+    constexpr uint32_t kWaveRegion = kScan >= 2 ? kWaveCandBytes : kWaveListBytes;
     uint16_t* candBase = reinterpret_cast<uint16_t*>(smem);
     float4* tabBase = smem + (256 / kWaveSize) * (kWaveRegion / 16);
     SceneTabs T;
@@ -1107,7 +1122,10 @@ __global__ void __launch_bounds__(256) k_unit_closest(const TraceParams p, const
     int idx = -1;
     unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)dbg;
-    if (kScan != 0) {
+    if (kScan == 3) {
+        const GridParams G{T.gridCells, p.grid_nu, p.grid_nv, p.grid_ax_u, p.grid_ax_v, p.grid_g0u, p.grid_g0v, p.grid_inv_h, p.grid_rmax_over_h};
+        scan_list_grid(T.scan, T.leaf, T.orig, G, T.gridCells, p.n_always, p.tree_box, p.bound_norm, o, d, live, tmin, idx, waveCand, lane);
+    } else if (kScan != 0) {
         scan_list_mfma<kScan == 2>(T.scan, T.leaf, T.orig, T.ops, T.nTiles, T.nTop, T.tree, p.level_off, p.n_levels, p.bound_norm, p.single_mask, p.n_always, p.tree_box_on ? p.tree_box : nullptr, o, d, live,
                                    tmin, idx, waveCand, lane, dbg);
     } else if (live) {

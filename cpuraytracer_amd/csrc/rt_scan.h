@@ -193,8 +193,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 constexpr uint32_t kTreeWork = RT_TREE_WORK, kTreeExact = RT_TREE_EXACT, kTreeReserve = 3 * kMaxLevels;  // hierarchy scan: (ray, node) and (ray, sphere) lists
 constexpr uint32_t kFarDrain = 128;                                     // hierarchy scan: exact entries that trigger a drain (far limits, below)
-constexpr uint32_t kPoolA = 640;                                        // pooled resolve: (ray, group) items per pass
-constexpr uint32_t kPoolB = 512;                                        // pooled resolve: (ray, sphere) items before a drain
+#ifndef RT_POOL_A
+#define RT_POOL_A 640
+#endif
+#ifndef RT_POOL_B
+#define RT_POOL_B 512
+#endif
+constexpr uint32_t kPoolA = RT_POOL_A;                                  // pooled resolve: (ray, group) items per pass
+constexpr uint32_t kPoolB = RT_POOL_B;                                  // pooled resolve: (ray, sphere) items before a drain
+static_assert(kPoolB > 4 * 64 && (kPoolA * 2 + kPoolB * 2) % 16 == 0, "a round may add 256 entries; the keys behind the pools are 8-byte aligned");
 constexpr uint32_t kWaveListBytes = kPoolA * 2 + kPoolB * 2 + 64 * 8;      // item pools + per-ray best keys = 2816 B per wave
 static_assert(kTreeExact >= kFarDrain + 4 * 64, "a round may add 256 entries to an exact list that holds up to kFarDrain - 1");
 constexpr uint32_t kWaveCandBytes = kTreeWork * 4 + kTreeExact * 4 + 64 * 8;  // hierarchy scan: 5888 B per wave
@@ -815,6 +822,265 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
         dbg[3] += mx;
     }
 #endif
+}
+
+// ------------------------------------------------ list scan through a uniform cell grid (large flat scenes)
+// Scenes too large for the flat matrix-core filter used to descend a hierarchy of bounding spheres (above): ~100 bound tests
+// per ray on the 10,004-sphere scene.  Such scenes are layers of small spheres: the host sorts the small spheres by their
+// HOME CELL in a uniform 2-D grid over the layer's two long axes (cell index iu * nv + iv, so the cells of one u-slab are
+// contiguous in v, and so are their spheres in the scan table: a run of cells IS a run of scan entries, no index lists), and
+// a ray only meets the spheres whose home cell lies within D cells (Chebyshev) of the part of the ray inside the layer's box:
+//   * the ray is clipped to the box around the small spheres, padded per ray by `reach`, the distance an accepted root's hit
+//     point can lie outside its sphere (the argument of the hierarchy's box clip above): roots lie in [tn, tf];
+//   * the hit point of an accepted root of sphere i is within r_i + reach of c_i, so its home cell is within
+//     D = (r_max + reach) / h + slack cells of the segment's projection -- the walk below visits EVERY cell within D of the
+//     segment (u-slab by u-slab, front to back; within a slab the v-range of the segment over the slab widened by D), a
+//     superset computed with slack for its own float rounding;
+//   * per (ray, run of <= 4 cells) item the pooled consumer tests the one-sphere bounds of the run's spheres (the same
+//     conservative test, near and far limits included, as the hierarchy's last level) and the survivors go to the exact list,
+//     drained by the same pooled reference-order phase with the ds_min_u64 merge.
+// The big spheres (at most eight) are tested exactly for every live ray first; their hits are the first far limits, and a ray
+// stops walking once the next slab starts beyond its closest hit so far.  Which spheres are TESTED never changes a result:
+// the exact phase is Sphere::Intersect in the reference's order and the merge is (t, original index).
+struct GridParams {
+    const uint16_t* cellStart;  // [nu * nv + 1] first scan entry of each cell (cell = iu * nv + iv)
+    uint32_t nu, nv;
+    uint32_t axU, axV;          // which coordinates span the grid (the third is the layer's thin axis)
+    float g0u, g0v, invH;       // grid origin and 1 / cell size
+    float rmaxOverH;            // largest radius among the grid's spheres, in cells
+};
+// per-ray walk state packed into one register: iu | iuEnd << 8 | iv << 16 | ivEnd << 24 (grids of at most 255 x 255 cells);
+// 0xffffffff = nothing (left) to walk
+constexpr uint32_t kGridDone = 0xffffffffu;
+constexpr float kGridSlack = 1e-3f;  // cells: >= 40 x the rounding of a grid coordinate (|coordinate| <= 256 cells, 2^-24 relative)
+
+// The v-range (rows) of slab iu for a segment S -> E in grid coordinates, widened by D: rows [r0, r1] clamped to the grid, or
+// r0 > r1 when the slab is not within D of the segment.  Also the segment parameter s in [0, 1] at which the walk enters the slab.
+RT_DEV void grid_slab_rows(float su, float sv, float eu, float ev, float D, int iu, int nv, int& r0, int& r1, float& sEnter) {
+    const float du = eu - su, dv = ev - sv;
+    const float ulo = __builtin_fminf(su, eu), uhi = __builtin_fmaxf(su, eu);
+    // the part of the segment whose u lies within D of the slab [iu, iu + 1]
+    const float a = __builtin_fmaxf(ulo, (float)iu - D - kGridSlack), b = __builtin_fminf(uhi, (float)(iu + 1) + D + kGridSlack);
+    float vlo, vhi;
+    const bool steep = __builtin_fabsf(du) < 1e-4f * __builtin_fmaxf(__builtin_fabsf(dv), 1.f);
+    if (steep) {  // (nearly) parallel to v: the whole v-extent of the segment
+        vlo = __builtin_fminf(sv, ev);
+        vhi = __builtin_fmaxf(sv, ev);
+        sEnter = 0.f;
+    } else {
+        const float slope = dv / du;
+        const float va = __builtin_fmaf(a - su, slope, sv), vb = __builtin_fmaf(b - su, slope, sv);
+        const float pad = 1e-4f * __builtin_fabsf(slope);  // (u - su) is good to 4e-5 cells; times the slope
+        vlo = __builtin_fminf(va, vb) - pad;
+        vhi = __builtin_fmaxf(va, vb) + pad;
+        const float uNear = du > 0.f ? a : b;  // where the walk direction enters the slab's neighbourhood ...
+        // ... moved a slack towards the start; as a fraction of the segment
+        sEnter = __builtin_fminf(__builtin_fmaxf((__builtin_fabsf(uNear - su) - kGridSlack) / __builtin_fabsf(du), 0.f), 1.f);
+    }
+    if (a > b) {  // the slab is farther than D from the segment
+        r0 = 1;
+        r1 = 0;
+        return;
+    }
+    const float f0 = __builtin_floorf(vlo - D - kGridSlack), f1 = __builtin_floorf(vhi + D + kGridSlack);
+    r0 = f0 < 0.f ? 0 : (int)f0;
+    r1 = f1 > (float)(nv - 1) ? nv - 1 : (int)f1;
+    if (f1 < 0.f) r1 = -1;
+}
+
+RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restrict__ leaf, const uint32_t* __restrict__ orig,
+                           const GridParams G, const uint16_t* __restrict__ cellStart, uint32_t nAlways, const float* treeBox, float boundNorm,
+                           V3 o, V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand, uint32_t lane) {
+    const float a = dot3(d, d);
+    tmin = __builtin_inff();
+    idx = -1;
+    const float dO = dot3(d, o);
+    const float m2a = -2.f * a;
+    const float gx = m2a * o.x, gy = m2a * o.y, gz = m2a * o.z;
+    const float oo = dot3(o, o);
+    const float aoo = a * oo;
+    const float bt = 1e-4f * __builtin_sqrtf(a) * (__builtin_sqrtf(oo) + boundNorm);
+    uint32_t* work = reinterpret_cast<uint32_t*>(waveCand);               // kTreeWork items: ray << 26 | cells - 1 << 24 | first cell
+    uint32_t* exact = work + kTreeWork;                                   // kTreeExact entries: ray << 16 | scan entry
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(exact + kTreeExact);
+    best[lane] = ~0ull;
+    wave_lds_handoff();
+    uint32_t nWork = 0, nExact = 0;
+    // the ray clipped to the padded box of the grid's spheres (the derivation is the hierarchy scan's, above)
+    float boxUn = -__builtin_inff(), boxUf = __builtin_inff();
+    uint32_t walk = kGridDone;
+    float su = 0.f, sv = 0.f, eu = 0.f, ev = 0.f, D = 0.f, tn = 0.f, tf = 0.f;
+    {
+        tf = __builtin_inff();
+        const float oc[3] = {o.x, o.y, o.z}, dc[3] = {d.x, d.y, d.z};
+        const float X = 32.f * 5.9604645e-8f * __builtin_fmaf(2.f, oo, treeBox[7]);
+        const float reach = __builtin_fminf(__builtin_sqrtf(X), X * treeBox[8]);
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const float pad = reach + 1e-6f * (__builtin_fabsf(oc[ax]) + treeBox[6]);
+            const float inv = __builtin_amdgcn_rcpf(dc[ax]);
+            const float t0 = ((treeBox[ax] - pad) - oc[ax]) * inv, t1 = ((treeBox[3 + ax] + pad) - oc[ax]) * inv;
+            tn = __builtin_fmaxf(tn, __builtin_fminf(t0, t1));
+            tf = __builtin_fminf(tf, __builtin_fmaxf(t0, t1));
+        }
+        tn *= 1.f - 0x1p-10f;
+        tf *= 1.f + 0x1p-10f;
+        const bool hitsBox = live && !(tn > tf || !(tf > 0.f)) && tf < 3.0e38f;
+        if (tn > 0.f) boxUn = a * tn;
+        boxUf = a * tf;
+        if (hitsBox) {
+            const float ou = G.axU == 0u ? o.x : (G.axU == 1u ? o.y : o.z), ov = G.axV == 0u ? o.x : (G.axV == 1u ? o.y : o.z);
+            const float du = G.axU == 0u ? d.x : (G.axU == 1u ? d.y : d.z), dv = G.axV == 0u ? d.x : (G.axV == 1u ? d.y : d.z);
+            su = (__builtin_fmaf(tn, du, ou) - G.g0u) * G.invH;
+            sv = (__builtin_fmaf(tn, dv, ov) - G.g0v) * G.invH;
+            eu = (__builtin_fmaf(tf, du, ou) - G.g0u) * G.invH;
+            ev = (__builtin_fmaf(tf, dv, ov) - G.g0v) * G.invH;
+            // points are good to ~1e-5 scene units x 1/h here (|t d| <= the scene's size); the slack of the walk covers it
+            D = G.rmaxOverH + reach * G.invH + kGridSlack;
+            const float fa = __builtin_floorf(__builtin_fminf(su, eu) - D - kGridSlack), fb = __builtin_floorf(__builtin_fmaxf(su, eu) + D + kGridSlack);
+            const int iuA = fa < 0.f ? 0 : (int)fa, iuB = fb > (float)(G.nu - 1u) ? (int)G.nu - 1 : (int)fb;
+            if (iuA <= iuB && fb >= 0.f) {
+                const bool fwd = eu >= su;
+                const int first = fwd ? iuA : iuB, last = fwd ? iuB : iuA;
+                walk = (uint32_t)first | (uint32_t)last << 8 | 0x00ff0000u;  // iv = 255 > ivEnd = 0: the first slab's rows are not set yet
+            }
+        }
+    }
+    auto drainExact = [&]() {
+        wave_lds_handoff();  // exact-list entries written by other lanes
+        for (uint32_t base = 0; base < nExact; base += kWaveSize) {
+            const uint32_t k = base + lane;
+            const bool has = k < nExact;
+            const uint32_t ent = has ? exact[k] : 0u;
+            const uint32_t r = ent >> 16, cand = ent & 0xffffu;
+            const float rox = lane_fetch(r, o.x), roy = lane_fetch(r, o.y), roz = lane_fetch(r, o.z);
+            const float rdx = lane_fetch(r, d.x), rdy = lane_fetch(r, d.y), rdz = lane_fetch(r, d.z);
+            const float ra = lane_fetch(r, a);
+            const float4 S = tab[cand];
+            const float ocx = rox - S.x;
+            const float ocy = roy - S.y;
+            const float ocz = roz - S.z;
+            const float b = (ocx * rdx + ocy * rdy) + ocz * rdz;
+            const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;
+            const float e = b * b - ra * cc;
+            const float sq = __builtin_sqrtf(e);
+            float t = (-b - sq) / ra;               // ray-tracing.cpp:56
+            if (!(t > 0.001f)) t = (-b + sq) / ra;  // :69
+            if (has && e > 0.f && t > 0.001f && t < __builtin_inff()) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((orig[cand] << 16) | cand);
+                __hip_atomic_fetch_min(best + r, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        nExact = 0;
+        wave_lds_handoff();  // the exact list may be refilled from here on
+    };
+    // the big spheres: one exact slot per live ray each; their hits are the walk's first far limits
+    for (uint32_t q = 0; q < nAlways; ++q) {
+        if (nExact + (uint32_t)kWaveSize > kTreeExact) drainExact();
+        const uint64_t lm = __ballot(live);
+        if (live) exact[nExact + prefix_count(lm)] = lane << 16 | (4u * q);
+        nExact += (uint32_t)__popcll(lm);
+    }
+    if (nExact != 0u) drainExact();
+    const int nv = (int)G.nv;
+    for (;;) {
+        // feed: every lane whose walk is not finished adds its next run of <= 4 cells, until a round's worth of items is listed
+        while (nWork < (uint32_t)kWaveSize && __ballot(walk != kGridDone) != 0ull) {
+            bool add = false;
+            uint32_t item = 0;
+            if (walk != kGridDone) {
+                int iu = (int)(walk & 255u), iv = (int)((walk >> 16) & 255u), ivEnd = (int)(walk >> 24);
+                const int iuEnd = (int)((walk >> 8) & 255u);
+                const int step = eu >= su ? 1 : -1;
+                bool done = false;
+                // rows not set (iv > ivEnd): take the rows of slab iu, or of the next slab that has any
+                while (iv > ivEnd && !done) {
+                    int r0, r1;
+                    float sEnter;
+                    grid_slab_rows(su, sv, eu, ev, D, iu, nv, r0, r1, sEnter);
+                    // a slab the walk enters beyond the ray's closest hit so far ends the walk: every later slab starts farther
+                    const uint32_t tb = reinterpret_cast<const uint32_t*>(best + lane)[1];
+                    const float tEnter = __builtin_fmaf(sEnter, tf - tn, tn);
+                    if (tb < 0x7f800000u && tEnter > __uint_as_float(tb) * (1.f + 0x1p-10f)) {
+                        done = true;
+                    } else if (r0 <= r1) {
+                        iv = r0;
+                        ivEnd = r1;
+                    } else if (iu == iuEnd) {
+                        done = true;
+                    } else {
+                        iu += step;
+                    }
+                }
+                if (done) {
+                    walk = kGridDone;
+                } else {
+                    const int cnt = (ivEnd - iv + 1) < 4 ? (ivEnd - iv + 1) : 4;
+                    item = lane << 26 | (uint32_t)(cnt - 1) << 24 | ((uint32_t)iu * (uint32_t)nv + (uint32_t)iv);
+                    add = true;
+                    iv += cnt;
+                    if (iv <= ivEnd) walk = (uint32_t)iu | (uint32_t)iuEnd << 8 | (uint32_t)iv << 16 | (uint32_t)ivEnd << 24;
+                    else if (iu == iuEnd) walk = kGridDone;
+                    else walk = (uint32_t)(iu + step) | (uint32_t)iuEnd << 8 | 0x00ff0000u;  // next slab, rows not set (iv 255 > ivEnd 0)
+                }
+            }
+            const uint64_t am = __ballot(add);
+            if (add) work[nWork + prefix_count(am)] = item;
+            nWork += (uint32_t)__popcll(am);
+        }
+        if (nWork == 0u) break;
+        wave_lds_handoff();  // items pushed by other lanes
+        const uint32_t np = nWork < (uint32_t)kWaveSize ? nWork : (uint32_t)kWaveSize;
+        const bool has = lane < np;
+        const uint32_t ent = has ? work[nWork - 1u - lane] : 0u;
+        nWork -= np;
+        wave_lds_handoff();  // popped slots are free for the next feed
+        const uint32_t r = ent >> 26, cells = ((ent >> 24) & 3u) + 1u, c0 = ent & 0xffffffu;
+        const V3 fg = v3(lane_fetch(r, gx), lane_fetch(r, gy), lane_fetch(r, gz));
+        const V3 fd = v3(lane_fetch(r, d.x), lane_fetch(r, d.y), lane_fetch(r, d.z));
+        const float fa = lane_fetch(r, a), fdO = lane_fetch(r, dO), faoo = lane_fetch(r, aoo), fbt = lane_fetch(r, bt);
+        const float fun = lane_fetch(r, boxUn), fuf = lane_fetch(r, boxUf);
+        const float fcr = faoo * (1.f - 2.f * kMarginKLeaf * 5.9604645e-8f);
+        uint32_t eb = has ? (uint32_t)cellStart[c0] : 0u;
+        const uint32_t ee = has ? (uint32_t)cellStart[c0 + cells] : 0u;
+        // four spheres per step; every lane runs as many steps as the longest run of the round needs
+        while (__ballot(eb < ee) != 0ull) {
+            const uint32_t tbits = reinterpret_cast<const uint32_t*>(best + r)[1];  // far limit: the ray's closest hit so far
+            float fu = tbits < 0x7f800000u ? (fa * __uint_as_float(tbits)) * (1.f + 0x1p-10f) : __builtin_inff();
+            fu = __builtin_fminf(fu, fuf);
+            uint32_t rb = 0u;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t e = eb + q;
+                const float4 B = leaf[e < ee ? e : 0u];  // (entry 0 is always there; its result is masked)
+                const int rej = e < ee ? bound_rejected_span(B, fg, fd, fa, fdO, fcr, fbt, fun, fu) : -1;
+                rb = __builtin_amdgcn_alignbit(rb, (uint32_t)rej, 31);
+            }
+            const uint32_t m = ~rb & 15u;  // bit 3-q = entry eb + q
+            if (nExact >= kFarDrain) drainExact();  // early and often: every exact round may pull the far limits in
+            {
+                const uint32_t nh = (uint32_t)__builtin_popcount(m);
+                const uint32_t incl = wave_inclusive_sum(nh);
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                uint32_t* wp = exact + nExact + (incl - nh);
+                uint32_t mm = m;
+                while (mm != 0u) {
+                    const uint32_t bit = 31u - (uint32_t)__builtin_clz(mm);
+                    mm &= ~(1u << bit);
+                    *wp++ = r << 16 | (eb + (3u - bit));
+                }
+                nExact += tot;
+            }
+            eb += 4u;
+        }
+    }
+    drainExact();
+    const unsigned long long mineKey = best[lane];  // behind drainExact's closing hand-off
+    const uint32_t tb = (uint32_t)(mineKey >> 32);
+    if (tb < 0x7f800000u) {
+        tmin = __uint_as_float(tb);
+        idx = (int)(mineKey & 0xffffull);
+    }
 }
 
 

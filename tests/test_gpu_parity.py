@@ -832,6 +832,9 @@ def _render_with_env(monkeypatch, env, sc, W, H, s1, depth=50, seed=1):
     {"RT_TILE_ORDER": "0"},                                    # tiles in image order instead of expensive-first
     {"RT_SINGLE_DIRECT": "0"},                                 # one-sphere groups through the sphere-level filter like the rest
     {"RT_QUEUE_BLOCK": "256", "RT_QUEUE_STATIC": "0"},         # queue geometry: bigger blocks, nothing static
+    {"RT_STASH": "0"},                                         # the prepared-path cache variants instead of the hit stash
+    {"RT_STASH": "0", "RT_RAY_CACHE": "0"},                    # neither: idle lanes generate their own paths
+    {"RT_STASH_CAP": "16"}, {"RT_STASH_CAP": "63"},            # smallest and largest stash
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_launch_and_layout_knobs_give_the_same_bits(hip, scenes_mod, monkeypatch, env):
     W, H, s1 = 161, 103, 5  # ragged: the last tile of the sample buffer is 9 pixels wide
@@ -849,11 +852,15 @@ def test_launch_and_layout_knobs_give_the_same_bits(hip, scenes_mod, monkeypatch
 
 
 @pytest.mark.parametrize("env", [{"RT_TREE_LDS": "0"}, {"RT_TREE_LDS": "0", "RT_SHADOW_GRID": "0"}, {"RT_BLOCK_THREADS": "512"},
-                                 {"RT_MATS_LDS": "0", "RT_TREE_TOP": "32"}, {"RT_ALWAYS_BIG": "1"}],
+                                 {"RT_MATS_LDS": "0", "RT_TREE_TOP": "32"}, {"RT_ALWAYS_BIG": "1"},
+                                 {"RT_GRID": "0"}, {"RT_GRID": "0", "RT_TREE_LDS": "0", "RT_STASH": "0"}, {"RT_GRID": "0", "RT_BLOCK_THREADS": "512"},
+                                 {"RT_STASH": "0"}, {"RT_STASH": "0", "RT_RAY_CACHE": "0"}, {"RT_BLOCK_THREADS": "256", "RT_BLOCKS_PER_CU": "2"},
+                                 {"RT_STASH_CAP": "17"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_hierarchy_scan_knobs_give_the_same_bits(hip, scenes_mod, monkeypatch, env):
-    """grid10k (2,504 groups, four levels of bounds): bounds through L2 instead of LDS, smaller workgroups, a narrower top level,
-    the big spheres inside the hierarchy (RT_ALWAYS_BIG=1) instead of tested for every ray."""
+    """grid10k (10,004 spheres: the cell-grid scan by default): the bounds hierarchy instead (RT_GRID=0: 2,504 groups, four levels of
+    bounds, through LDS or L2, a narrower top level, the big spheres inside it with RT_ALWAYS_BIG=1), smaller workgroups, the path
+    cache instead of the hit stash, neither, a small stash."""
     sc = scenes_mod.build_scene("grid10k", 1, 96, 96)
     hip.upload(sc)
     sa = hip.render(96, 96, 1, 3, 50, 1)
