@@ -173,7 +173,7 @@ struct SceneLayout {
     bool gridOn = false;
     std::vector<uint16_t> gridCellStart;  // [nu * nv + 1]
     uint32_t gridNu = 0, gridNv = 0, gridAxU = 0, gridAxV = 2;
-    float gridG0u = 0.f, gridG0v = 0.f, gridInvH = 0.f, gridRmaxOverH = 0.f;
+    float gridG0u = 0.f, gridG0v = 0.f, gridInvH = 0.f, gridRmaxOverH = 0.f, gridBigNorm = 0.f;
 };
 
 // Conservative bounding sphere of a set of spheres, in the filter's (C, |C|^2 - Rf^2) form.
@@ -367,7 +367,7 @@ static bool BoxOf(const rt_sphere* sp, const std::vector<uint32_t>& ids, float t
 // run of scan entries -- about 1.5 spheres per cell, at most 254 x 254 cells.  false: the scene does not suit (the caller builds
 // the bounds hierarchy instead).
 static bool BuildGridLayout(const rt_sphere* sp, uint32_t n, const std::vector<uint32_t>& big, const std::vector<uint32_t>& small, SceneLayout& L) {
-    if (big.size() > 8 || small.size() < 512) return false;
+    if (big.size() > 8 || small.size() < 256) return false;
     if (!BoxOf(sp, small, L.treeBox)) return false;
     const double ext[3] = {(double)L.treeBox[3] - L.treeBox[0], (double)L.treeBox[4] - L.treeBox[1], (double)L.treeBox[5] - L.treeBox[2]};
     int w = 0;
@@ -428,7 +428,7 @@ static bool BuildGridLayout(const rt_sphere* sp, uint32_t n, const std::vector<u
     L.leaf.assign(L.scan.size(), BoundOf(sp, {}, nullptr, rtd::kMarginKLeaf));
     L.boundNorm = 0.f;
     for (size_t e = 0; e < L.orig.size(); ++e)
-        if (L.orig[e] != 0xffffffffu) L.leaf[e] = BoundOf(sp, {L.orig[e]}, e >= base ? &L.boundNorm : nullptr, rtd::kMarginKLeaf);
+        if (L.orig[e] != 0xffffffffu) L.leaf[e] = BoundOf(sp, {L.orig[e]}, e >= base ? &L.boundNorm : &L.gridBigNorm, rtd::kMarginKLeaf);
     L.nAlways = (uint32_t)big.size();
     // one level of group bounds for rt_unit_layout's readers (the scan does not use them); the big spheres' groups are out of it
     L.tree.clear();
@@ -459,7 +459,8 @@ static void BuildLayout(const rt_sphere* sp, uint32_t n, uint32_t topMax, SceneL
     {
         const char* g = std::getenv("RT_GRID");
         const bool wantGrid = !(g && g[0] == '0') && std::getenv("RT_ALWAYS_BIG") == nullptr;
-        if (wantGrid && (small.size() + 3) / 4 + big.size() > topMax && BuildGridLayout(sp, n, big, small, L)) return;
+        const bool force = g && g[0] == '2';  // RT_GRID=2 (experiments): the grid for every scene it can be built for
+        if (wantGrid && ((small.size() + 3) / 4 + big.size() > topMax || force) && BuildGridLayout(sp, n, big, small, L)) return;
         L = SceneLayout{};
     }
     // k-d median split down to leaves of four, emitted in tree order: compact, balanced groups whose
@@ -692,7 +693,7 @@ static size_t MfmaOpsBytesFor(uint32_t nGroups) { return (size_t)rtd::mfma_tiles
 // entry, so that it runs the scan rt_render runs): tree = hierarchy scan <false, ., 2>, flat = matrix-core filter over the
 // groups with every table in LDS <true, ., 1>, else the VALU scan with (ldsTables) or without LDS tables.
 struct TraceVariant {
-    bool tree, flat, ldsTables, grid;
+    bool tree, flat, ldsTables, grid, gridLds;
     size_t candBytes, leafBytes;
 };
 static TraceVariant ChooseVariant(const rt_ctx* ctx, const rtd::TraceParams& tp) {
@@ -708,6 +709,9 @@ static TraceVariant ChooseVariant(const rt_ctx* ctx, const rtd::TraceParams& tp)
     V.leafBytes = (size_t)tp.n_padded * 16;  // one-sphere bounds, staged next to the scan table by the flat scan
     V.flat = !V.tree && !V.grid && useLds && ctx->useMfma && (V.candBytes + lds + V.leafBytes + MfmaOpsBytesFor(topCnt)) <= 160 * 1024;
     V.ldsTables = useLds && !V.tree && !V.grid;
+    // a grid scene whose tables all fit LDS next to the grid scan's work lists (small scenes laid out for the grid: RT_GRID=2)
+    V.gridLds = V.grid && useLds && ctx->matsInLds && ctx->blockThreads == 1024 &&
+                V.candBytes + lds + V.leafBytes + ((size_t)tp.grid_nu * tp.grid_nv + 1) * 2 + 16 <= 128 * 1024;
     return V;
 }
 
@@ -772,8 +776,12 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     const bool tree = V.tree, flat = V.flat, ldsTables = V.ldsTables;
     const uint32_t topCnt = tp.level_cnt[tp.n_levels - 1];
     const size_t candBytes = V.candBytes, leafBytes = V.leafBytes;
-    size_t sgBytes = (flat && tp.sg_enabled) ? (((size_t)tp.sg_nx * tp.sg_ny + 1 + tp.sg_nentries + tp.sg_nglobal) * 2 + 15) / 16 * 16 : 0;
-    if (candBytes + lds + leafBytes + MfmaOpsBytesFor(topCnt) + sgBytes > 160 * 1024) sgBytes = 0;  // index stays in global memory (L2)
+    bool gridLds = V.gridLds;
+    size_t sgBytes = ((flat || gridLds) && tp.sg_enabled) ? (((size_t)tp.sg_nx * tp.sg_ny + 1 + tp.sg_nentries + tp.sg_nglobal) * 2 + 15) / 16 * 16 : 0;
+    if (candBytes + lds + leafBytes + (flat ? MfmaOpsBytesFor(topCnt) : 0) + sgBytes + (gridLds ? ((size_t)tp.grid_nu * tp.grid_nv + 1) * 2 + 16 : 0) > 160 * 1024) {
+        sgBytes = 0;  // index stays in global memory (L2)
+        if (tp.sg_enabled) gridLds = false;  // ... and the all-in-LDS grid variant needs it there
+    }
     tp.sg_in_lds = sgBytes ? 1u : 0u;
     size_t treeBytes = tree ? (size_t)(tp.level_off[tp.n_levels - 1] + topCnt) * 16 : 0;
     if (!ctx->treeInLds || candBytes + MfmaOpsBytesFor(topCnt) + treeBytes > 160 * 1024) treeBytes = 0;
@@ -783,7 +791,7 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     size_t gridBytes = (grid && ctx->blockThreads == 1024) ? (((size_t)tp.grid_nu * tp.grid_nv + 1) * 2 + 15) / 16 * 16 : 0;
     if (candBytes + gridBytes > 160 * 1024) gridBytes = 0;  // (cannot happen below 60,000 cells)
     tp.grid_in_lds = gridBytes ? 1u : 0u;
-    size_t ldsBytes = candBytes + (ldsTables ? lds : 0) + (flat ? leafBytes : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0) + sgBytes + treeBytes + gridBytes;
+    size_t ldsBytes = candBytes + ((ldsTables || gridLds) ? lds : 0) + ((flat || gridLds) ? leafBytes : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0) + sgBytes + treeBytes + gridBytes;
     // per-wave caches of prepared paths go last, when there is room left (RT_RAY_CACHE=0 disables them)
     ldsBytes = (ldsBytes + 15) / 16 * 16;
     tp.ray_cache_off16 = 0;
@@ -814,7 +822,7 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     }
     if (std::getenv("RT_VERBOSE"))
         std::fprintf(stderr, "rt_trace launch: tree=%d flat=%d ldsTables=%d blocks=%u threads=%u lds=%zu B (cand %zu, tables %zu, leaf %zu, ops %zu, sg %zu, tree %zu, cache %s, stash %u)\n",
-                     (int)tree, (int)flat, (int)ldsTables, blocks, ctx->blockThreads, ldsBytes, candBytes, ldsTables ? lds : (size_t)0, flat ? leafBytes : (size_t)0,
+                     (int)tree, (int)flat + 2 * (int)grid + 4 * (int)gridLds, (int)ldsTables, blocks, ctx->blockThreads, ldsBytes, candBytes, ldsTables ? lds : (size_t)0, flat ? leafBytes : (size_t)0,
                      (flat || tree) ? MfmaOpsBytesFor(topCnt) : (size_t)0, sgBytes, treeBytes, (tp.ray_cache_off16 && !useStash) ? "yes" : "no", tp.stash_cap);
     // flat variant with the hit-processing tables provably in LDS (typed pointers: no flat loads) when they all fit
     const bool hitLds = flat && tp.mats_in_lds && (sgBytes != 0 || !tp.sg_enabled);
@@ -847,6 +855,9 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
         else RT_LAUNCH(LDS, 256, M);                                   \
     } while (0)
     if (carryMode == 2) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 1, true, true, true>));
+    else if (gridLds && useStash && tp.grid_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 3, true, true, false, true>));
+    else if (gridLds && tp.grid_in_lds && tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 3, true, true>));
+    else if (gridLds && tp.grid_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 3, false, true>));
     else if (grid && ctx->blockThreads == 1024 && useStash && tp.grid_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 3, true, true, false, true>));
     else if (grid && ctx->blockThreads == 1024 && tp.grid_in_lds && tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 3, true, true>));
     else if (grid && ctx->blockThreads == 1024 && tp.grid_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 3, false, true>));
@@ -1281,6 +1292,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
         b.grid_g0v = L.gridG0v;
         b.grid_inv_h = L.gridInvH;
         b.grid_rmax_over_h = L.gridRmaxOverH;
+        b.grid_big_norm = L.gridBigNorm;
     }
     b.sg_enabled = SG.enabled ? 1u : 0u;
     if (SG.enabled) {

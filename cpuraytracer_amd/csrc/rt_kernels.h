@@ -131,7 +131,8 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
     if (kLds) {
         float4* ldsScan = tabBase;
         float4* ldsLeaf = ldsScan + p.n_padded;
-        uint32_t* ldsOrig = reinterpret_cast<uint32_t*>(ldsLeaf + (kScan == 1 ? p.n_padded : 0u));
+        constexpr bool kLeafLds = kScan == 1 || kScan == 3;  // the scans that test one-sphere bounds from LDS
+        uint32_t* ldsOrig = reinterpret_cast<uint32_t*>(ldsLeaf + (kLeafLds ? p.n_padded : 0u));
         float4* ldsMat = reinterpret_cast<float4*>(ldsOrig + p.n_padded);  // n_padded is a multiple of 4
         const uint32_t nMatLds = (kHitLds || p.mats_in_lds) ? p.n_padded : 0u;
         float* ldsRad = reinterpret_cast<float*>(ldsMat + (size_t)nMatLds * 3);
@@ -139,10 +140,27 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
         for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) {
             ldsScan[k] = p.scan[k];
             ldsOrig[k] = p.orig[k];
-            if (kScan == 1) ldsLeaf[k] = p.leaf[k];
+            if (kLeafLds) ldsLeaf[k] = p.leaf[k];
         }
         for (uint32_t k = threadIdx.x; k < nMatLds * 3; k += blockDim.x) ldsMat[k] = gMat[k];
         for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) ldsRad[k] = p.radius[k];
+        if (kScan == 3) {
+            // cell-grid scan with every table in LDS (kHitLds by construction): the cells' first entries, then the shadow index
+            uint16_t* gc = reinterpret_cast<uint16_t*>(ldsRad + p.n_padded);
+            const uint32_t ng = p.grid_nu * p.grid_nv + 1u;
+            for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) gc[k] = p.grid_cell_start[k];
+            T.gridCells = gc;
+            uint16_t* g = gc + ((ng + 7u) & ~7u);  // 16-byte steps
+            const uint32_t nc = p.sg_nx * p.sg_ny + 1u;
+            if (p.sg_enabled) {
+                for (uint32_t k = threadIdx.x; k < nc; k += blockDim.x) g[k] = p.sg_cell_start[k];
+                for (uint32_t k = threadIdx.x; k < p.sg_nentries; k += blockDim.x) g[nc + k] = p.sg_entries[k];
+                for (uint32_t k = threadIdx.x; k < p.sg_nglobal; k += blockDim.x) g[nc + p.sg_nentries + k] = p.sg_global[k];
+            }
+            T.sgCell = g;
+            T.sgEntries = g + nc;
+            T.sgGlobal = g + nc + p.sg_nentries;
+        }
         if (kMfma) {
             float* ldsOps = ldsRad + p.n_padded;  // a multiple of 4
             build_mfma_operands(p.tree + p.level_off[topLevel], nTop, nTiles, ldsOps, threadIdx.x, blockDim.x);
@@ -173,7 +191,7 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
         __syncthreads();
         T.scan = ldsScan;
         T.orig = ldsOrig;
-        if (kScan == 1) T.leaf = ldsLeaf;
+        if (kLeafLds) T.leaf = ldsLeaf;
         T.rad = ldsRad;
         if (kHitLds) T.mats = reinterpret_cast<const rt_material*>(ldsMat);
         else if (p.mats_in_lds) T.mats = reinterpret_cast<const rt_material*>(ldsMat);
@@ -728,7 +746,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
             scan_list_mfma<kScan == 2>(scanTab, leafTab, origTab, mfmaOps, nTiles, nTop, treeTab, p.level_off, p.n_levels, p.bound_norm, p.single_mask, p.n_always, p.tree_box_on ? p.tree_box : nullptr, ro, rd,
                                        live, tmin, idx, waveCand, lane, dbgScan);
         } else if (kScan == 3) {
-            const GridParams G{gridCells, p.grid_nu, p.grid_nv, p.grid_ax_u, p.grid_ax_v, p.grid_g0u, p.grid_g0v, p.grid_inv_h, p.grid_rmax_over_h};
+            const GridParams G{gridCells, p.grid_nu, p.grid_nv, p.grid_ax_u, p.grid_ax_v, p.grid_g0u, p.grid_g0v, p.grid_inv_h, p.grid_rmax_over_h, p.grid_big_norm};
             scan_list_grid(scanTab, leafTab, origTab, G, gridCells, p.n_always, p.tree_box, p.bound_norm, ro, rd, live, tmin, idx, waveCand, lane);
         } else if (live) {
             scan_list_deferred(scanTab, origTab, p.n_padded, ro, rd, tmin, idx, cand);
@@ -1123,7 +1141,7 @@ __global__ void __launch_bounds__(256) k_unit_closest(const TraceParams p, const
     unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)dbg;
     if (kScan == 3) {
-        const GridParams G{T.gridCells, p.grid_nu, p.grid_nv, p.grid_ax_u, p.grid_ax_v, p.grid_g0u, p.grid_g0v, p.grid_inv_h, p.grid_rmax_over_h};
+        const GridParams G{T.gridCells, p.grid_nu, p.grid_nv, p.grid_ax_u, p.grid_ax_v, p.grid_g0u, p.grid_g0v, p.grid_inv_h, p.grid_rmax_over_h, p.grid_big_norm};
         scan_list_grid(T.scan, T.leaf, T.orig, G, T.gridCells, p.n_always, p.tree_box, p.bound_norm, o, d, live, tmin, idx, waveCand, lane);
     } else if (kScan != 0) {
         scan_list_mfma<kScan == 2>(T.scan, T.leaf, T.orig, T.ops, T.nTiles, T.nTop, T.tree, p.level_off, p.n_levels, p.bound_norm, p.single_mask, p.n_always, p.tree_box_on ? p.tree_box : nullptr, o, d, live,

@@ -133,7 +133,7 @@ struct TraceParams {
     // Cell-grid scan (rt_scan.h scan_list_grid; large flat scenes): the small spheres are stored sorted by home cell behind the big ones
     const uint16_t* grid_cell_start;  // [grid_nu * grid_nv + 1] first scan entry of each cell, or null: no grid for this scene
     uint32_t grid_nu, grid_nv, grid_ax_u, grid_ax_v, grid_in_lds;
-    float grid_g0u, grid_g0v, grid_inv_h, grid_rmax_over_h;
+    float grid_g0u, grid_g0v, grid_inv_h, grid_rmax_over_h, grid_big_norm;
     // Exact shadow index for the (single, directional) sun: spheres binned by their footprint in the plane
     // perpendicular to the light.  Valid for hit points with |p|^2 <= sg_p0sq.
     const uint16_t* sg_cell_start;  // [sg_nx * sg_ny + 1]

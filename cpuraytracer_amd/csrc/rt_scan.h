@@ -836,9 +836,11 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
 //     D = (r_max + reach) / h + slack cells of the segment's projection -- the walk below visits EVERY cell within D of the
 //     segment (u-slab by u-slab, front to back; within a slab the v-range of the segment over the slab widened by D), a
 //     superset computed with slack for its own float rounding;
-//   * per (ray, run of <= 4 cells) item the pooled consumer tests the one-sphere bounds of the run's spheres (the same
-//     conservative test, near and far limits included, as the hierarchy's last level) and the survivors go to the exact list,
-//     drained by the same pooled reference-order phase with the ds_min_u64 merge.
+//   * the work is POOLED over the wave like the other scans: a ray lists (ray, slab) items, up to four per feed pass, front to
+//     back; any lane takes an item, fetches that ray from its owner (ds_bpermute), computes the slab's rows, and tests the
+//     one-sphere bounds of the spheres of those cells, four per step (the same conservative test, near and far limits
+//     included, as the hierarchy's last level); the survivors go to the exact list, drained by the same pooled
+//     reference-order phase with the ds_min_u64 merge.
 // The big spheres (at most eight) are tested exactly for every live ray first; their hits are the first far limits, and a ray
 // stops walking once the next slab starts beyond its closest hit so far.  Which spheres are TESTED never changes a result:
 // the exact phase is Sphere::Intersect in the reference's order and the merge is (t, original index).
@@ -848,10 +850,8 @@ struct GridParams {
     uint32_t axU, axV;          // which coordinates span the grid (the third is the layer's thin axis)
     float g0u, g0v, invH;       // grid origin and 1 / cell size
     float rmaxOverH;            // largest radius among the grid's spheres, in cells
+    float bigNorm;              // max |c| + r over the big spheres (the scale of their bounds' behind-the-origin threshold)
 };
-// per-ray walk state packed into one register: iu | iuEnd << 8 | iv << 16 | ivEnd << 24 (grids of at most 255 x 255 cells);
-// 0xffffffff = nothing (left) to walk
-constexpr uint32_t kGridDone = 0xffffffffu;
 constexpr float kGridSlack = 1e-3f;  // cells: >= 40 x the rounding of a grid coordinate (|coordinate| <= 256 cells, 2^-24 relative)
 
 // The v-range (rows) of slab iu for a segment S -> E in grid coordinates, widened by D: rows [r0, r1] clamped to the grid, or
@@ -900,7 +900,8 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
     const float oo = dot3(o, o);
     const float aoo = a * oo;
     const float bt = 1e-4f * __builtin_sqrtf(a) * (__builtin_sqrtf(oo) + boundNorm);
-    uint32_t* work = reinterpret_cast<uint32_t*>(waveCand);               // kTreeWork items: ray << 26 | cells - 1 << 24 | first cell
+    const float crLeaf = aoo * (1.f - 2.f * kMarginKLeaf * 5.9604645e-8f);
+    uint32_t* work = reinterpret_cast<uint32_t*>(waveCand);               // kTreeWork items: ray << 8 | slab
     uint32_t* exact = work + kTreeWork;                                   // kTreeExact entries: ray << 16 | scan entry
     unsigned long long* best = reinterpret_cast<unsigned long long*>(exact + kTreeExact);
     best[lane] = ~0ull;
@@ -908,10 +909,10 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
     uint32_t nWork = 0, nExact = 0;
     // the ray clipped to the padded box of the grid's spheres (the derivation is the hierarchy scan's, above)
     float boxUn = -__builtin_inff(), boxUf = __builtin_inff();
-    uint32_t walk = kGridDone;
-    float su = 0.f, sv = 0.f, eu = 0.f, ev = 0.f, D = 0.f, tn = 0.f, tf = 0.f;
+    float su = 0.f, sv = 0.f, eu = 0.f, ev = 0.f, D = 0.f, tn = 0.f, tf = __builtin_inff();
+    int slab = 0, slabLast = 0, slabStep = 1;  // the ray's next slab, its last one, the walk's direction (front to back)
+    bool pending = false;
     {
-        tf = __builtin_inff();
         const float oc[3] = {o.x, o.y, o.z}, dc[3] = {d.x, d.y, d.z};
         const float X = 32.f * 5.9604645e-8f * __builtin_fmaf(2.f, oo, treeBox[7]);
         const float reach = __builtin_fminf(__builtin_sqrtf(X), X * treeBox[8]);
@@ -941,8 +942,10 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
             const int iuA = fa < 0.f ? 0 : (int)fa, iuB = fb > (float)(G.nu - 1u) ? (int)G.nu - 1 : (int)fb;
             if (iuA <= iuB && fb >= 0.f) {
                 const bool fwd = eu >= su;
-                const int first = fwd ? iuA : iuB, last = fwd ? iuB : iuA;
-                walk = (uint32_t)first | (uint32_t)last << 8 | 0x00ff0000u;  // iv = 255 > ivEnd = 0: the first slab's rows are not set yet
+                slab = fwd ? iuA : iuB;
+                slabLast = fwd ? iuB : iuA;
+                slabStep = fwd ? 1 : -1;
+                pending = true;
             }
         }
     }
@@ -974,105 +977,110 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
         nExact = 0;
         wave_lds_handoff();  // the exact list may be refilled from here on
     };
-    // the big spheres: one exact slot per live ray each; their hits are the walk's first far limits
+    // The big spheres (at most eight, entries 4q): the owner lane tests its own ray against the sphere's one-sphere bound --
+    // the floor is hit by most rays, the others by few -- and the survivors take one exact slot each; their hits are the walk's
+    // first far limits.
+    const float btBig = 1e-4f * __builtin_sqrtf(a) * (__builtin_sqrtf(oo) + G.bigNorm);
     for (uint32_t q = 0; q < nAlways; ++q) {
         if (nExact + (uint32_t)kWaveSize > kTreeExact) drainExact();
-        const uint64_t lm = __ballot(live);
-        if (live) exact[nExact + prefix_count(lm)] = lane << 16 | (4u * q);
+        const bool cand = live && bound_rejected(leaf[4u * q], v3(gx, gy, gz), d, a, dO, crLeaf, btBig) >= 0;
+        const uint64_t lm = __ballot(cand);
+        if (cand) exact[nExact + prefix_count(lm)] = lane << 16 | (4u * q);
         nExact += (uint32_t)__popcll(lm);
     }
     if (nExact != 0u) drainExact();
     const int nv = (int)G.nv;
+    constexpr uint32_t kFeed = 4;  // slabs a ray lists per feed pass (a pass adds at most 64 * kFeed items)
+    static_assert(kTreeWork >= 64u * kFeed, "one feed pass must fit the work list");
     for (;;) {
-        // feed: every lane whose walk is not finished adds its next run of <= 4 cells, until a round's worth of items is listed
-        while (nWork < (uint32_t)kWaveSize && __ballot(walk != kGridDone) != 0ull) {
-            bool add = false;
-            uint32_t item = 0;
-            if (walk != kGridDone) {
-                int iu = (int)(walk & 255u), iv = (int)((walk >> 16) & 255u), ivEnd = (int)(walk >> 24);
-                const int iuEnd = (int)((walk >> 8) & 255u);
-                const int step = eu >= su ? 1 : -1;
-                bool done = false;
-                // rows not set (iv > ivEnd): take the rows of slab iu, or of the next slab that has any
-                while (iv > ivEnd && !done) {
-                    int r0, r1;
-                    float sEnter;
-                    grid_slab_rows(su, sv, eu, ev, D, iu, nv, r0, r1, sEnter);
-                    // a slab the walk enters beyond the ray's closest hit so far ends the walk: every later slab starts farther
-                    const uint32_t tb = reinterpret_cast<const uint32_t*>(best + lane)[1];
-                    const float tEnter = __builtin_fmaf(sEnter, tf - tn, tn);
-                    if (tb < 0x7f800000u && tEnter > __uint_as_float(tb) * (1.f + 0x1p-10f)) {
-                        done = true;
-                    } else if (r0 <= r1) {
-                        iv = r0;
-                        ivEnd = r1;
-                    } else if (iu == iuEnd) {
-                        done = true;
-                    } else {
-                        iu += step;
-                    }
+        // feed: every ray with slabs left lists its next (up to) kFeed of them, front to back -- (ray, slab) is all an item says;
+        // a ray whose next slab begins beyond its closest hit so far is done
+        while (nWork + 64u * kFeed <= kTreeWork && __ballot(pending) != 0ull) {
+            uint32_t cnt = 0;
+            if (pending) {
+                const uint32_t left = (uint32_t)((slabLast - slab) * slabStep) + 1u;
+                cnt = left < kFeed ? left : kFeed;
+                const uint32_t tb = reinterpret_cast<const uint32_t*>(best + lane)[1];
+                if (tb < 0x7f800000u) {
+                    // where the walk enters the neighbourhood of slab `slab` (grid_slab_rows' sEnter), against the far limit
+                    const float du = eu - su;
+                    const float uNear = du > 0.f ? __builtin_fmaxf(__builtin_fminf(su, eu), (float)slab - D - kGridSlack)
+                                                 : __builtin_fminf(__builtin_fmaxf(su, eu), (float)(slab + 1) + D + kGridSlack);
+                    const bool steep = __builtin_fabsf(du) < 1e-4f * __builtin_fmaxf(__builtin_fabsf(ev - sv), 1.f);
+                    const float sEnter = steep ? 0.f : __builtin_fminf(__builtin_fmaxf((__builtin_fabsf(uNear - su) - kGridSlack) / __builtin_fabsf(du), 0.f), 1.f);
+                    if (__builtin_fmaf(sEnter, tf - tn, tn) > __uint_as_float(tb) * (1.f + 0x1p-10f)) cnt = 0;  // every later slab starts farther still
                 }
-                if (done) {
-                    walk = kGridDone;
-                } else {
-                    const int cnt = (ivEnd - iv + 1) < 4 ? (ivEnd - iv + 1) : 4;
-                    item = lane << 26 | (uint32_t)(cnt - 1) << 24 | ((uint32_t)iu * (uint32_t)nv + (uint32_t)iv);
-                    add = true;
-                    iv += cnt;
-                    if (iv <= ivEnd) walk = (uint32_t)iu | (uint32_t)iuEnd << 8 | (uint32_t)iv << 16 | (uint32_t)ivEnd << 24;
-                    else if (iu == iuEnd) walk = kGridDone;
-                    else walk = (uint32_t)(iu + step) | (uint32_t)iuEnd << 8 | 0x00ff0000u;  // next slab, rows not set (iv 255 > ivEnd 0)
-                }
+                if (cnt == 0u) pending = false;
             }
-            const uint64_t am = __ballot(add);
-            if (add) work[nWork + prefix_count(am)] = item;
-            nWork += (uint32_t)__popcll(am);
+            const uint32_t incl = wave_inclusive_sum(cnt);
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t* wp = work + nWork + (incl - cnt);
+            for (uint32_t k = 0; k < cnt; ++k) wp[k] = lane << 8 | (uint32_t)(slab + (int)k * slabStep);
+            if (cnt != 0u) {
+                if ((uint32_t)((slabLast - slab) * slabStep) + 1u == cnt) pending = false;
+                slab += (int)cnt * slabStep;
+            }
+            nWork += tot;
         }
         if (nWork == 0u) break;
-        wave_lds_handoff();  // items pushed by other lanes
-        const uint32_t np = nWork < (uint32_t)kWaveSize ? nWork : (uint32_t)kWaveSize;
-        const bool has = lane < np;
-        const uint32_t ent = has ? work[nWork - 1u - lane] : 0u;
-        nWork -= np;
-        wave_lds_handoff();  // popped slots are free for the next feed
-        const uint32_t r = ent >> 26, cells = ((ent >> 24) & 3u) + 1u, c0 = ent & 0xffffffu;
-        const V3 fg = v3(lane_fetch(r, gx), lane_fetch(r, gy), lane_fetch(r, gz));
-        const V3 fd = v3(lane_fetch(r, d.x), lane_fetch(r, d.y), lane_fetch(r, d.z));
-        const float fa = lane_fetch(r, a), fdO = lane_fetch(r, dO), faoo = lane_fetch(r, aoo), fbt = lane_fetch(r, bt);
-        const float fun = lane_fetch(r, boxUn), fuf = lane_fetch(r, boxUf);
-        const float fcr = faoo * (1.f - 2.f * kMarginKLeaf * 5.9604645e-8f);
-        uint32_t eb = has ? (uint32_t)cellStart[c0] : 0u;
-        const uint32_t ee = has ? (uint32_t)cellStart[c0 + cells] : 0u;
-        // four spheres per step; every lane runs as many steps as the longest run of the round needs
-        while (__ballot(eb < ee) != 0ull) {
-            const uint32_t tbits = reinterpret_cast<const uint32_t*>(best + r)[1];  // far limit: the ray's closest hit so far
-            float fu = tbits < 0x7f800000u ? (fa * __uint_as_float(tbits)) * (1.f + 0x1p-10f) : __builtin_inff();
-            fu = __builtin_fminf(fu, fuf);
-            uint32_t rb = 0u;
+        wave_lds_handoff();  // items listed by other lanes
+        // consume the whole list in the order it was fed: 64 (ray, slab) items per round
+        for (uint32_t base = 0; base < nWork; base += kWaveSize) {
+            const bool has = base + lane < nWork;
+            const uint32_t ent = has ? work[base + lane] : 0u;
+            const uint32_t r = ent >> 8;
+            const int iu = (int)(ent & 255u);
+            const V3 fg = v3(lane_fetch(r, gx), lane_fetch(r, gy), lane_fetch(r, gz));
+            const V3 fd = v3(lane_fetch(r, d.x), lane_fetch(r, d.y), lane_fetch(r, d.z));
+            const float fa = lane_fetch(r, a), fdO = lane_fetch(r, dO), fcr = lane_fetch(r, crLeaf), fbt = lane_fetch(r, bt);
+            const float fun = lane_fetch(r, boxUn), fuf = lane_fetch(r, boxUf);
+            const float fsu = lane_fetch(r, su), fsv = lane_fetch(r, sv), feu = lane_fetch(r, eu), fev = lane_fetch(r, ev), fD = lane_fetch(r, D);
+            int r0, r1;
+            float sEnter;
+            grid_slab_rows(fsu, fsv, feu, fev, fD, iu, nv, r0, r1, sEnter);
+            uint32_t eb = 0u, ee = 0u;
+            if (has && r0 <= r1) {
+                // the slab's cells r0..r1 are consecutive, and so are their spheres in the scan table
+                eb = (uint32_t)cellStart[iu * nv + r0];
+                ee = (uint32_t)cellStart[iu * nv + r1 + 1];
+                // (a slab the ray enters beyond its closest hit so far has nothing to add)
+                const uint32_t tb0 = reinterpret_cast<const uint32_t*>(best + r)[1];
+                const float ftn = fun > 0.f ? fun / fa : 0.f;  // tn and tf back from the box limits a * t
+                if (tb0 < 0x7f800000u && __builtin_fmaf(sEnter, fuf / fa - ftn, ftn) > __uint_as_float(tb0) * (1.f + 0x1p-9f)) ee = eb;
+            }
+            // four spheres per step; every lane runs as many steps as the longest run of the round needs
+            while (__ballot(eb < ee) != 0ull) {
+                const uint32_t tbits = reinterpret_cast<const uint32_t*>(best + r)[1];  // far limit: the ray's closest hit so far
+                float fu = tbits < 0x7f800000u ? (fa * __uint_as_float(tbits)) * (1.f + 0x1p-10f) : __builtin_inff();
+                fu = __builtin_fminf(fu, fuf);
+                uint32_t rb = 0u;
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) {
-                const uint32_t e = eb + q;
-                const float4 B = leaf[e < ee ? e : 0u];  // (entry 0 is always there; its result is masked)
-                const int rej = e < ee ? bound_rejected_span(B, fg, fd, fa, fdO, fcr, fbt, fun, fu) : -1;
-                rb = __builtin_amdgcn_alignbit(rb, (uint32_t)rej, 31);
-            }
-            const uint32_t m = ~rb & 15u;  // bit 3-q = entry eb + q
-            if (nExact >= kFarDrain) drainExact();  // early and often: every exact round may pull the far limits in
-            {
-                const uint32_t nh = (uint32_t)__builtin_popcount(m);
-                const uint32_t incl = wave_inclusive_sum(nh);
-                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                uint32_t* wp = exact + nExact + (incl - nh);
-                uint32_t mm = m;
-                while (mm != 0u) {
-                    const uint32_t bit = 31u - (uint32_t)__builtin_clz(mm);
-                    mm &= ~(1u << bit);
-                    *wp++ = r << 16 | (eb + (3u - bit));
+                for (uint32_t q = 0; q < 4; ++q) {
+                    const uint32_t e = eb + q;
+                    const float4 B = leaf[e < ee ? e : 0u];  // (entry 0 is always there; its result is masked)
+                    const int rej = e < ee ? bound_rejected_span(B, fg, fd, fa, fdO, fcr, fbt, fun, fu) : -1;
+                    rb = __builtin_amdgcn_alignbit(rb, (uint32_t)rej, 31);
                 }
-                nExact += tot;
+                const uint32_t m = ~rb & 15u;  // bit 3-q = entry eb + q
+                if (nExact >= kFarDrain) drainExact();  // early and often: every exact round may pull the far limits in
+                {
+                    const uint32_t nh = (uint32_t)__builtin_popcount(m);
+                    const uint32_t incl = wave_inclusive_sum(nh);
+                    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    uint32_t* wp = exact + nExact + (incl - nh);
+                    uint32_t mm = m;
+                    while (mm != 0u) {
+                        const uint32_t bit = 31u - (uint32_t)__builtin_clz(mm);
+                        mm &= ~(1u << bit);
+                        *wp++ = r << 16 | (eb + (3u - bit));
+                    }
+                    nExact += tot;
+                }
+                eb += 4u;
             }
-            eb += 4u;
         }
+        nWork = 0;
+        wave_lds_handoff();  // the list is free for the next feed
     }
     drainExact();
     const unsigned long long mineKey = best[lane];  // behind drainExact's closing hand-off
@@ -1082,6 +1090,5 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
         idx = (int)(mineKey & 0xffffull);
     }
 }
-
 
 }  // namespace rtd

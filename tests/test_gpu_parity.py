@@ -835,6 +835,9 @@ def _render_with_env(monkeypatch, env, sc, W, H, s1, depth=50, seed=1):
     {"RT_STASH": "0"},                                         # the prepared-path cache variants instead of the hit stash
     {"RT_STASH": "0", "RT_RAY_CACHE": "0"},                    # neither: idle lanes generate their own paths
     {"RT_STASH_CAP": "16"}, {"RT_STASH_CAP": "63"},            # smallest and largest stash
+    {"RT_GRID": "2"},                                          # the cell-grid scan (tables in LDS) instead of the matrix-core filter
+    {"RT_GRID": "2", "RT_MATS_LDS": "0"},                      # ... with its tables through L2
+    {"RT_GRID": "2", "RT_STASH": "0", "RT_SHADOW_GRID": "0"},
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_launch_and_layout_knobs_give_the_same_bits(hip, scenes_mod, monkeypatch, env):
     W, H, s1 = 161, 103, 5  # ragged: the last tile of the sample buffer is 9 pixels wide
