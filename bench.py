@@ -11,7 +11,7 @@ Inputs (scene tables) are resident in HBM before the timed region starts.
         N > 1: spp = 128 * N, image rows sharded cyclically across ranks, one RCCL gather of the strips
         to rank 0 per step (configs[2] is N = 8: spp 1024).  Per-GPU work is constant: weak scaling.
 --config c4: configs[3], cover scene, aperture 2.0, 1920x1080, spp 512 (divergent lens sampling).
---config c5: configs[4], grid10k (10,004 spheres), 4096x4096, spp 64 (the bounds-hierarchy scan).
+--config c5: configs[4], grid10k (10,004 spheres), 4096x4096, spp 64 (the cell-grid scan).
 The line has the same shape for every config; the driver's headline run is the default.
 
 Launch: python bench.py --gpus 1 ...   or
@@ -21,7 +21,7 @@ Rank 0 prints ONE JSON line.
 
 roofline: the trace kernel is bound by VALU ISSUE (the matrix cores share the SIMD's
 issue port).  `achieved` = executed VALU lane-operations per launch (SQ_THREAD_CYCLES_VALU = SQ_INSTS_VALU x 64 x
-lane utilisation, from the committed rocprofv3 --pmc passes of this same command, profiles/r02_pmc_summary*.json)
+lane utilisation, from the committed rocprofv3 --pmc passes of this same command, profiles/r03_pmc_summary*.json)
 divided by the launch duration measured LIVE in this run with HIP events on the kernel's stream; `peak` = 78.6 T
 lane-op/s (256 CU x 4 SIMD x 64 lanes / 2 cycles x 2.4 GHz).  The instruction counts are a property of (kernel
 binary, workload): the PMC summary records the hash of the kernel sources it was taken from, and the roofline object
@@ -43,13 +43,13 @@ SCENE_SEED, RENDER_SEED = 1, 1
 CONFIGS = {
     # name: scene, W, H, spp per GPU, aperture (-1 = the scene's own), metric text, PMC summary
     "c2": dict(scene="cover", W=1200, H=800, spp=128, aperture=-1.0,
-               metric="Msamples/sec (WxHxspp/s), 1200x800 cover scene spp=128 d=50", pmc="r02_pmc_summary.json"),
+               metric="Msamples/sec (WxHxspp/s), 1200x800 cover scene spp=128 d=50", pmc="r03_pmc_summary.json"),
     "c3": dict(scene="cover", W=1200, H=800, spp=1024, aperture=-1.0,  # BASELINE config 3's whole job on ONE GPU: one 11.8 GB pass
-               metric="Msamples/sec (WxHxspp/s), 1200x800 cover scene spp=1024 d=50", pmc="r02_pmc_summary_c3.json"),
+               metric="Msamples/sec (WxHxspp/s), 1200x800 cover scene spp=1024 d=50", pmc="r03_pmc_summary_c3.json"),
     "c4": dict(scene="cover", W=1920, H=1080, spp=512, aperture=2.0,
-               metric="Msamples/sec (WxHxspp/s), 1920x1080 cover scene aperture=2.0 spp=512 d=50", pmc="r02_pmc_summary_c4.json"),
+               metric="Msamples/sec (WxHxspp/s), 1920x1080 cover scene aperture=2.0 spp=512 d=50", pmc="r03_pmc_summary_c4.json"),
     "c5": dict(scene="grid10k", W=4096, H=4096, spp=64, aperture=-1.0,
-               metric="Msamples/sec (WxHxspp/s), 4096x4096 grid10k scene (10,004 spheres) spp=64 d=50", pmc="r02_pmc_summary_c5.json"),
+               metric="Msamples/sec (WxHxspp/s), 4096x4096 grid10k scene (10,004 spheres) spp=64 d=50", pmc="r03_pmc_summary_c5.json"),
 }
 PEAK_VALU_TLANEOPS = 78.6   # 256 CU x 4 SIMD x 64 lanes / 2 cycles per wave-instruction x 2.4 GHz (MI355X_MICROARCH.md: SIMD-32, 2 cycles)
 PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
@@ -298,8 +298,8 @@ def main():
         if os.environ.get("RT_BENCH_DUMP_LDR"):  # tests: the gathered image of the last step
             import numpy as np
             np.save(os.environ["RT_BENCH_DUMP_LDR"], full)
-        kernel_name = ("rt_trace_kernel<bounds hierarchy, 1024 threads, matrix-core top level + pooled descent, path cache>" if args.config == "c5"
-                       else "rt_trace_kernel<LDS tables, 1024 threads, matrix-core filter, path cache>")
+        kernel_name = ("rt_trace_kernel<cell-grid scan, 1024 threads, pooled slab items, hit stash>" if args.config == "c5"
+                       else "rt_trace_kernel<LDS tables, 1024 threads, matrix-core filter, hit stash>")
         roofline, cull = roofline_object(cfg, kernel_name, avg_ms, avg_trav, n_spheres, kernel_sources_hash(), n_gpus=N)
         per_rank, slowest = per_rank_report(rank_rows)
         out = {

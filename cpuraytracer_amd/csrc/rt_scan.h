@@ -990,7 +990,10 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
     }
     if (nExact != 0u) drainExact();
     const int nv = (int)G.nv;
-    constexpr uint32_t kFeed = 4;  // slabs a ray lists per feed pass (a pass adds at most 64 * kFeed items)
+#ifndef RT_GRID_FEED
+#define RT_GRID_FEED 4
+#endif
+    constexpr uint32_t kFeed = RT_GRID_FEED;  // slabs a ray lists per feed pass (a pass adds at most 64 * kFeed items)
     static_assert(kTreeWork >= 64u * kFeed, "one feed pass must fit the work list");
     for (;;) {
         // feed: every ray with slabs left lists its next (up to) kFeed of them, front to back -- (ray, slab) is all an item says;

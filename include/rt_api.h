@@ -180,8 +180,11 @@ int rt_set_sampler(rt_ctx* ctx, uint32_t flags);
  * next call's kernel.  Planes are added to the HDR strip strictly in sample order as they complete, so after a flush the
  * strip equals the one-shot render bit for bit.  While frames are in flight rt_resolve(ctx, 0) divides by the number of
  * samples actually in the strip (rt_committed_samples), and rt_download / rt_copy_to_device hand out that strip.
- * rt_synchronize, a call with statistics, rt_set_frame_pipelining itself and scenes the pipelined kernel variant does not
- * cover (deeper bounds hierarchy, non-default launch knobs) settle everything first / run unpipelined.  depth 0 = off. */
+ * rt_synchronize, a call with statistics and rt_set_frame_pipelining itself settle everything first.  depth 0 = off.
+ * SCOPE: the carrying kernel exists for scenes whose tables fit LDS with the matrix-core filter (up to 128 groups of four
+ * spheres, i.e. about 500 spheres: the reference's cover scene and everything smaller).  Larger scenes -- the cell-grid and
+ * bounds-hierarchy scans (10,000-sphere class) -- and contexts created under non-default launch knobs render every call
+ * UNPIPELINED: same results, each call runs its own paths to their end before the next one starts. */
 int rt_set_frame_pipelining(rt_ctx* ctx, uint32_t depth);
 /* Samples per pixel in the HDR strip right now (waits for the stream). */
 int rt_committed_samples(rt_ctx* ctx, uint32_t* out);

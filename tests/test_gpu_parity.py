@@ -1006,6 +1006,31 @@ def test_error_codes(hip, scenes_mod):
     r.close()
 
 
+def test_scene_size_limit_is_an_error_not_a_truncation(hip, oracle):
+    """Work lists, the shadow index and the closest-hit keys carry scan-entry ids in 16 bits: a scene beyond 65,535 scan entries
+    (about 65,000 spheres) is refused by rt_scene_upload with RT_ERR_INVALID_ARG; 60,000 spheres are accepted and render through
+    the cell-grid scan exactly like the oracle."""
+    from cpuraytracer_amd import HipRenderer, RtError
+    rng = np.random.default_rng(70)
+
+    def scene(n, side):
+        c = np.stack([rng.uniform(-side, side, n), np.full(n, 0.2), rng.uniform(-side, side, n)], 1).astype(np.float32)
+        c = np.concatenate([c, [[0.0, -1000.0, 0.0]]]).astype(np.float32)
+        r_ = np.concatenate([np.full(n, 0.2), [1000.0]]).astype(np.float32)
+        t = np.concatenate([rng.choice([0, 0, 0, 1, 2], n), [0]]).astype(np.uint32)
+        return _custom_scene(oracle, c, r_, t, (12.0, 2.0, -2.5), (0.0, 1.0, 0.0), 25.0, 1.5)
+    r = HipRenderer(0)
+    try:
+        with pytest.raises(RtError) as e:
+            r.upload(scene(70_000, 130.0))
+        assert e.value.code == 2 and "65,535" in str(e.value)
+        with pytest.raises(RtError):
+            r.render(8, 8, 1, 2, 8, 1)  # the refused upload left no scene behind
+    finally:
+        r.close()
+    _assert_image_equals_oracle(hip, oracle, scene(60_000, 120.0), 96, 64, 2, 20, seed=4)
+
+
 def test_cli_writes_the_same_ppm(hip, oracle, scenes_mod, tmp_path):
     import subprocess
     from conftest import ROOT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Full profile of bench.py for one config (run on the GPU box): bench line, rocprofv3 kernel stats, four PMC passes.
-# usage: tools/profile_round.sh <outdir under gpurun_out> [c2|c3|c4|c5]   then: python tools/summarize_profile.py gpurun_out/<outdir> profiles/r02 [c3|c4|c5]
+# usage: tools/profile_round.sh <outdir under gpurun_out> [c2|c3|c4|c5]   then: python tools/summarize_profile.py gpurun_out/<outdir> profiles/r03 [c3|c4|c5]
 export TMPDIR=/tmp
 d=gpurun_out/${1:-profR}
 cfg=${2:-c2}

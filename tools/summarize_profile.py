@@ -1,8 +1,8 @@
 """Turn a tools/profile_round.sh output directory (gpurun_out/<dir>) into the committed summaries under profiles/:
   <prefix>_bench_line.json, <prefix>_bench_under_rocprof.json, <prefix>_bench_kernel_stats.csv,
   <prefix>_pmc_summary.json, <prefix>_hbm_traffic.json.
-usage: python tools/summarize_profile.py gpurun_out/profR2 profiles/r02 [c4|c5]
-(a config suffix gives profiles/r02_*_c4.json etc.; the default, headline config has none)"""
+usage: python tools/summarize_profile.py gpurun_out/profR2 profiles/r03 [c3|c4|c5]
+(a config suffix gives profiles/r03_*_c4.json etc.; the default, headline config has none)"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
