@@ -13,7 +13,8 @@ static void Usage() {
     std::puts("usage: spheres [--width N] [--height N] [--spp N] [--frame-spp N] [--depth N] [--fov F] [--aperture F]\n"
               "               [--scene cover|three|grid10k] [--scene-seed N] [--seed N] [--device N] [--gpus N] [--out file.ppm] [--quiet]\n"
               "               [--sampler reference|cosine|sqrtdisk|cosine+sqrtdisk]   (default: the reference's mappings)\n"
-              "               [--pipeline N]   frames in flight for quiet progressive runs (--frame-spp 1 --quiet); 0 = off");
+              "               [--pipeline N]   frames in flight for quiet progressive runs (--frame-spp 1 --quiet); 0 = off\n"
+              "               [--batch N]      quiet progressive frames rendered per launch (rt_set_frame_batch); 1 = off");
 }
 
 int main(int argc, char** argv) {
@@ -43,6 +44,7 @@ int main(int argc, char** argv) {
         else if (k == "--out") out = val();
         else if (k == "--quiet") quiet = true;
         else if (k == "--pipeline") st.framesInFlight = (uint32_t)std::atoi(val());
+        else if (k == "--batch") st.framesPerLaunch = (uint32_t)std::atoi(val());
         else if (k == "--sampler") {
             const std::string v = val();
             st.samplerFlags = (v.find("cosine") != std::string::npos ? RT_SAMPLER_COSINE_HEMISPHERE : 0u) |

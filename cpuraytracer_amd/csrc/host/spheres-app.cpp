@@ -168,6 +168,7 @@ size_t SpheresApp::DrawBitmap() {  // spheres-app.cpp:163-222
         RT_CALL(rt_scene_upload(m_device, spheres.data(), materials.data(), (uint32_t)spheres.size(), &camera, &sun, &sky, exposureAdjustment));
         RT_CALL(rt_set_sampler(m_device, AppSettings.samplerFlags));
         RT_CALL(rt_set_frame_pipelining(m_device, AppSettings.framesInFlight));
+        RT_CALL(rt_set_frame_batch(m_device, AppSettings.framesPerLaunch ? AppSettings.framesPerLaunch : 1u));
         m_uploaded = true;
     }
     const rt_rowset rs = m_hasRowset ? m_rowset : rt_rowset{0, H, H, 0, 1};

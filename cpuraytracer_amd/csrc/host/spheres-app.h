@@ -26,6 +26,7 @@ struct AppSettingsT {
     uint64_t renderSeed = 1;      // per-path xoshiro stream seed
     uint32_t samplesPerFrame = 1; // the reference adds one sample per frame (spheres-app.cpp:168)
     uint32_t framesInFlight = 0;  // rt_set_frame_pipelining: frames whose unfinished paths may ride along into later frames (0 = off)
+    uint32_t framesPerLaunch = 1; // rt_set_frame_batch: quiet frames rendered per launch (1 = off)
     uint32_t samplerFlags = 0;    // RT_SAMPLER_* (rt_api.h): 0 = the reference's uniform hemisphere and linear-r lens disk
 };
 

@@ -132,6 +132,12 @@ struct rt_ctx {
     uint32_t pipeSppCap = 0, pipeNpix = 0, pipeRing = 0;  // geometry of the ring: samples per region, pixels, regions
     uint32_t pipeInSel = 0;     // which continuation buffer the next trace kernel reads
     uint32_t pipeCommits = 0;   // commit kernels launched since the pipeline started (FrameCtl: which entry is current)
+    // frame batching (rt_set_frame_batch): stats-less rt_render calls wait here until batchFrames sample planes are pending
+    uint32_t batchFrames = 1;
+    bool pendOn = false;
+    uint32_t pendW = 0, pendH = 0, pendS0 = 0, pendS1 = 0, pendDepth = 0;
+    rt_rowset pendRs{};
+    uint64_t pendSeed = 0;
     uint32_t pipeMaxDepth = 0;  // max_depth and seed of the running pipeline (a flush re-launches with them)
     uint64_t pipeSeed = 0;
     rtd::RegionTable pipeRegions{};
@@ -1207,10 +1213,14 @@ void rt_destroy(rt_ctx* ctx) {
     delete ctx;
 }
 
+static int BatchFlush(rt_ctx* ctx);  // frame batching (rt_set_frame_batch), next to rt_render
+
 int rt_set_stream(rt_ctx* ctx, void* hip_stream) {
     if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_set_stream: null ctx");
-    {   // frames in flight belong to the old stream: settle them there first
+    {   // pending frames and frames in flight belong to the old stream: settle them there first
         RT_HIP(hipSetDevice(ctx->device));
+        const int rcb = BatchFlush(ctx);
+        if (rcb != RT_OK) return rcb;
         const int rcf = PipelineFlush(ctx);
         if (rcf != RT_OK) return rcf;
     }
@@ -1230,6 +1240,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
         return Fail(RT_ERR_INVALID_ARG, "rt_scene_upload: null pointer or empty scene");
     RT_HIP(hipSetDevice(ctx->device));
     int rc;
+    if ((rc = BatchFlush(ctx)) != RT_OK) return rc;  // pending frames were asked of the scene that is being replaced
     SceneLayout L;
     BuildLayout(spheres, n, ctx->treeTop, L);
     // work lists, the shadow index and the closest-hit keys carry scan-entry ids in 16 bits
@@ -1356,7 +1367,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
 int rt_set_frame_pipelining(rt_ctx* ctx, uint32_t depth) {
     if (!ctx || depth > rtd::kMaxFramesInFlight - 2u) return Fail(RT_ERR_INVALID_ARG, "rt_set_frame_pipelining: depth must be 0..14");
     RT_HIP(hipSetDevice(ctx->device));
-    int rc = PipelineFlush(ctx);
+    int rc = BatchFlush(ctx);
+    if (rc != RT_OK) return rc;
+    rc = PipelineFlush(ctx);
     ctx->pipeDepth = depth;
     return rc;
 }
@@ -1377,6 +1390,7 @@ int rt_committed_samples(rt_ctx* ctx, uint32_t* out) {
 int rt_set_sampler(rt_ctx* ctx, uint32_t flags) {
     if (!ctx || (flags & ~(RT_SAMPLER_COSINE_HEMISPHERE | RT_SAMPLER_SQRT_DISK)) != 0u) return Fail(RT_ERR_INVALID_ARG, "rt_set_sampler: unknown flag");
     if (flags != ctx->sampler) {
+        ctx->pendOn = false;   // (pending frames of the old mapping are dropped with the accumulation they belonged to)
         ctx->accumulated = 0;  // samples of two mappings do not mix: the next rt_render starts over
         PipelineDrop(ctx);
         ctx->tileOrderValid = false;  // the pilot rays use the lens mapping
@@ -1387,6 +1401,7 @@ int rt_set_sampler(rt_ctx* ctx, uint32_t flags) {
 
 int rt_clear(rt_ctx* ctx) {
     if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_clear: null ctx");
+    ctx->pendOn = false;
     PipelineDrop(ctx);
     ctx->accumulated = 0;
     return RT_OK;
@@ -1399,9 +1414,57 @@ uint32_t rt_rowset_global_row(rt_rowset rs, uint32_t lr) {
     return rs.first_row + (lb * rs.nshards + rs.shard) * rs.block_rows + k;
 }
 
+static int RenderNow(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1, uint32_t max_depth, uint64_t seed,
+                     rt_stats* out_stats);
+
+// Frame batching: render the pending sample planes with ONE launch (no statistics, nothing waits for the device).
+static int BatchFlush(rt_ctx* ctx) {
+    if (!ctx->pendOn) return RT_OK;
+    ctx->pendOn = false;
+    return RenderNow(ctx, ctx->pendW, ctx->pendH, ctx->pendRs, ctx->pendS0, ctx->pendS1, ctx->pendDepth, ctx->pendSeed, nullptr);
+}
+
+int rt_set_frame_batch(rt_ctx* ctx, uint32_t frames) {
+    if (!ctx || frames == 0 || frames > 4096) return Fail(RT_ERR_INVALID_ARG, "rt_set_frame_batch: frames must be 1..4096");
+    RT_HIP(hipSetDevice(ctx->device));
+    const int rc = BatchFlush(ctx);
+    ctx->batchFrames = frames;
+    return rc;
+}
+
 int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1, uint32_t max_depth, uint64_t seed,
               rt_stats* out_stats) {
     if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_render: null ctx");
+    if (ctx->batchFrames > 1 && out_stats == nullptr && ctx->pipeDepth == 0 && ctx->hasScene && W != 0 && H != 0 && s0 != 0 && s1 > s0) {
+        // a pending batch this call does not continue is rendered first, as the calls were made
+        if (ctx->pendOn && !(ctx->pendW == W && ctx->pendH == H && std::memcmp(&ctx->pendRs, &rs, sizeof(rs)) == 0 && ctx->pendDepth == max_depth &&
+                             ctx->pendSeed == seed && ctx->pendS1 == s0)) {
+            const int rcf = BatchFlush(ctx);
+            if (rcf != RT_OK) return rcf;
+        }
+        if (!ctx->pendOn) {
+            // only a call that RenderNow would accept as the start or the continuation of an accumulation is deferred
+            const uint32_t rows = RowsetLocalRows(rs);
+            const bool sameStrip = ctx->W == W && ctx->H == H && ctx->rows == rows && std::memcmp(&ctx->rs, &rs, sizeof(rs)) == 0;
+            const bool starts = s0 == 1, continues = ctx->accumulated != 0 && sameStrip && s0 == ctx->accumulated + 1;
+            if (rows != 0 && (uint64_t)rs.first_row + rs.num_rows <= H && (starts || continues)) {
+                ctx->pendOn = true;
+                ctx->pendW = W; ctx->pendH = H; ctx->pendRs = rs; ctx->pendS0 = s0; ctx->pendDepth = max_depth; ctx->pendSeed = seed;
+            }
+        }
+        if (ctx->pendOn) {
+            ctx->pendS1 = s1;
+            if (ctx->pendS1 - ctx->pendS0 >= ctx->batchFrames) return BatchFlush(ctx);
+            return RT_OK;
+        }
+    }
+    const int rcb = BatchFlush(ctx);  // a call with statistics (or one that cannot be deferred) settles the pending batch first
+    if (rcb != RT_OK) return rcb;
+    return RenderNow(ctx, W, H, rs, s0, s1, max_depth, seed, out_stats);
+}
+
+static int RenderNow(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1, uint32_t max_depth, uint64_t seed,
+                     rt_stats* out_stats) {
     if (!ctx->hasScene) return Fail(RT_ERR_NO_SCENE, "rt_render: no scene uploaded");
     if (W == 0 || H == 0 || s0 == 0 || s1 <= s0) return Fail(RT_ERR_INVALID_ARG, "rt_render: empty image or sample range");
     const uint32_t rows = RowsetLocalRows(rs);
@@ -1560,6 +1623,10 @@ int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, ui
 
 int rt_resolve(rt_ctx* ctx, uint32_t n_samples) {
     if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_resolve: null ctx");
+    if (ctx->accumulated == 0 && ctx->pendOn) {  // nothing committed yet: the pending frames are what there is to show
+        const int rcb = BatchFlush(ctx);
+        if (rcb != RT_OK) return rcb;
+    }
     if (ctx->accumulated == 0) return Fail(RT_ERR_SEQUENCE, "rt_resolve: nothing accumulated");
     RT_HIP(hipSetDevice(ctx->device));
     const uint32_t n = n_samples ? n_samples : ctx->accumulated;
@@ -1582,6 +1649,10 @@ double rt_last_resolve_ms(rt_ctx* ctx) { return ctx ? ctx->lastResolveMs : 0.0; 
 
 int rt_download(rt_ctx* ctx, float* hdr_rgb, uint8_t* ldr_rgb) {
     if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_download: null ctx");
+    if (ctx->accumulated == 0 && ctx->pendOn) {
+        const int rcb = BatchFlush(ctx);
+        if (rcb != RT_OK) return rcb;
+    }
     if (ctx->accumulated == 0) return Fail(RT_ERR_SEQUENCE, "rt_download: nothing rendered");
     RT_HIP(hipSetDevice(ctx->device));
     const size_t npix = (size_t)ctx->W * ctx->rows;
@@ -1593,6 +1664,10 @@ int rt_download(rt_ctx* ctx, float* hdr_rgb, uint8_t* ldr_rgb) {
 
 int rt_copy_to_device(rt_ctx* ctx, void* dev_hdr_rgb, void* dev_ldr_rgb) {
     if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_copy_to_device: null ctx");
+    if (ctx->accumulated == 0 && ctx->pendOn) {
+        const int rcb = BatchFlush(ctx);
+        if (rcb != RT_OK) return rcb;
+    }
     if (ctx->accumulated == 0) return Fail(RT_ERR_SEQUENCE, "rt_copy_to_device: nothing rendered");
     RT_HIP(hipSetDevice(ctx->device));
     const size_t npix = (size_t)ctx->W * ctx->rows;
@@ -1604,7 +1679,9 @@ int rt_copy_to_device(rt_ctx* ctx, void* dev_hdr_rgb, void* dev_ldr_rgb) {
 int rt_synchronize(rt_ctx* ctx) {
     if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_synchronize: null ctx");
     RT_HIP(hipSetDevice(ctx->device));
-    int rcf = PipelineFlush(ctx);  // frames in flight are finished and committed first
+    int rcf = BatchFlush(ctx);  // pending frames are rendered,
+    if (rcf != RT_OK) return rcf;
+    rcf = PipelineFlush(ctx);  // frames in flight are finished and committed first
     if (rcf != RT_OK) return rcf;
     RT_HIP(hipStreamSynchronize(ctx->stream));
     return RT_OK;

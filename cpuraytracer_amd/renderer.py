@@ -45,6 +45,10 @@ class HipRenderer:
         """rt_set_frame_pipelining: up to `depth` stats-less render calls may stay in flight (0 = off)."""
         check(self._L.rt_set_frame_pipelining(self._h, int(depth)))
 
+    def set_frame_batch(self, frames):
+        """rt_set_frame_batch: stats-less render calls that continue each other are rendered `frames` sample planes per launch (1 = off)."""
+        check(self._L.rt_set_frame_batch(self._h, int(frames)))
+
     def committed_samples(self):
         n = C.c_uint32(0)
         check(self._L.rt_committed_samples(self._h, C.byref(n)))

@@ -186,6 +186,15 @@ int rt_set_sampler(rt_ctx* ctx, uint32_t flags);
  * bounds-hierarchy scans (10,000-sphere class) -- and contexts created under non-default launch knobs render every call
  * UNPIPELINED: same results, each call runs its own paths to their end before the next one starts. */
 int rt_set_frame_pipelining(rt_ctx* ctx, uint32_t depth);
+/* Frame batching for progressive use: a 1-spp frame is less work than the three launches it takes.  With frames > 1, rt_render
+ * calls that pass out_stats == NULL and continue each other (same image, row set, depth and seed; s0 == the previous s1) are
+ * only RECORDED until `frames` sample planes are pending; then ONE launch renders them all, and the planes are added to the
+ * HDR strip in sample order as always -- the strip equals what the separate calls would have produced, bit for bit.  Until
+ * then rt_resolve / rt_download / rt_copy_to_device hand out the samples committed so far (rt_committed_samples; when nothing
+ * is committed yet they render the pending frames first).  rt_synchronize, a call with statistics, a call that does not
+ * continue the batch, rt_scene_upload, rt_set_stream and rt_set_frame_batch itself render what is pending first; errors of
+ * deferred calls surface there.  Not combined with rt_set_frame_pipelining (depth > 0 takes precedence).  frames == 1: off. */
+int rt_set_frame_batch(rt_ctx* ctx, uint32_t frames);
 /* Samples per pixel in the HDR strip right now (waits for the stream). */
 int rt_committed_samples(rt_ctx* ctx, uint32_t* out);
 

@@ -671,6 +671,63 @@ def test_pipelined_progressive_frames_equal_the_one_shot_render(hip, scenes_mod,
         one.close()
 
 
+@pytest.mark.parametrize("scene,W,H,frames,spf,batch", [("cover", 161, 103, 41, 1, 8), ("cover", 320, 200, 13, 3, 4), ("grid10k", 96, 64, 30, 1, 16),
+                                                    ("three", 65, 1, 9, 1, 2)])
+def test_batched_progressive_frames_equal_the_one_shot_render(hip, scenes_mod, scene, W, H, frames, spf, batch):
+    """rt_set_frame_batch: stats-less frames that continue each other are rendered `batch` sample planes per launch (any scene
+    class).  (a) mid-stream the strip holds a whole number of batches and equals the one-shot render of exactly those samples;
+    (b) rt_synchronize renders the rest: the strip equals the one-shot render of all samples; (c) a call with statistics, and a
+    call that starts a new accumulation, settle what is pending first."""
+    from cpuraytracer_amd import HipRenderer
+    sc = scenes_mod.build_scene(scene, 1, W, H)
+    one = HipRenderer(0)
+    one.upload(sc)
+    hip.upload(sc)
+    try:
+        hip.set_frame_batch(batch)
+        for f in range(frames):
+            hip.render(W, H, 1 + f * spf, 1 + (f + 1) * spf, 50, 1, stats=False)
+            if f == frames // 2:
+                c = hip.committed_samples()
+                done = (f + 1) * spf
+                assert c <= done and done - c < batch + spf and c % spf == 0
+                if c > 0:
+                    hip.resolve()
+                    h_mid, l_mid = hip.download()
+                    one.render(W, H, 1, 1 + c, 50, 1)
+                    one.resolve()
+                    h_ref, l_ref = one.download()
+                    assert_same(h_mid, h_ref, "strip in mid-stream (%d of %d samples committed)" % (c, done))
+                    assert_same(l_mid, l_ref, "LDR in mid-stream")
+        hip.synchronize()
+        assert hip.committed_samples() == frames * spf
+        hip.resolve()
+        hdr, ldr = hip.download()
+        one.render(W, H, 1, 1 + frames * spf, 50, 1)
+        one.resolve()
+        h1, l1 = one.download()
+        assert_same(hdr, h1, "batched frames vs one shot")
+        assert_same(ldr, l1, "batched frames vs one shot, LDR")
+        # two more frames stay pending; a call with statistics renders them first and reports only its own samples
+        n0 = frames * spf
+        hip.render(W, H, 1 + n0, 1 + n0 + spf, 50, 1, stats=False)
+        assert hip.committed_samples() in (n0, n0 + spf)
+        st = hip.render(W, H, 1 + n0 + spf, 2 + n0 + spf, 50, 1)
+        assert st.samples == W * H and hip.committed_samples() == n0 + spf + 1
+        one.render(W, H, 1 + n0, 2 + n0 + spf, 50, 1)
+        assert_same(hip.download(ldr=False)[0], one.download(ldr=False)[0], "continuation after the batch")
+        # a pending frame followed by the start of a new accumulation: the old one is settled, the new one starts clean
+        hip.render(W, H, 2 + n0 + spf, 3 + n0 + spf, 50, 1, stats=False)
+        hip.render(W, H, 1, 2, 50, 7, stats=False)
+        hip.synchronize()
+        assert hip.committed_samples() == 1
+        one.render(W, H, 1, 2, 50, 7)
+        assert_same(hip.download(ldr=False)[0], one.download(ldr=False)[0], "new accumulation after a pending frame")
+    finally:
+        hip.set_frame_batch(1)
+        one.close()
+
+
 def test_pipelining_falls_back_where_the_variant_does_not_apply(hip, scenes_mod):
     """grid10k runs the hierarchy scan, which has no carrying variant: the same calls run unpipelined and stay exact."""
     sc = scenes_mod.build_scene("grid10k", 1, 96, 96)
@@ -1052,13 +1109,13 @@ def test_cli_progressive_frames_with_pipelining_write_the_one_shot_ppm(hip, tmp_
     from conftest import ROOT
     cli = os.path.join(ROOT, "cpuraytracer_amd", "lib", "spheres")
     outs = []
-    for extra in (["--frame-spp", "24"], ["--frame-spp", "1", "--pipeline", "6"]):
+    for extra in (["--frame-spp", "24"], ["--frame-spp", "1", "--pipeline", "6"], ["--frame-spp", "1", "--batch", "5"]):
         out = str(tmp_path / ("p%d.ppm" % len(outs)))
         p = subprocess.run([cli, "--scene", "cover", "--width", "240", "--height", "160", "--spp", "24", "--out", out, "--quiet"] + extra,
                            capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stderr
         outs.append(open(out, "rb").read())
-    assert outs[0] == outs[1] and len(outs[0]) == len(b"P6\n240 160\n255\n") + 240 * 160 * 3
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) == len(b"P6\n240 160\n255\n") + 240 * 160 * 3
 
 
 def test_cli_multi_gpu_driver_with_rccl_gather(hip, tmp_path):

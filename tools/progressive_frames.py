@@ -12,9 +12,14 @@ from cpuraytracer_amd import HipRenderer, scenes
 W, H, N = 1200, 800, 256
 sc = scenes.build_scene("cover", 1, W, H)
 one = HipRenderer(0); one.upload(sc); one.render(W, H, 1, N + 1, 50, 1); one.resolve(); h1, _ = one.download()
-for depth in [int(x) for x in os.environ.get("RT_DEPTHS", "0,2,4,8").split(",")]:
+MODES = [("pipelining depth", int(x)) for x in os.environ.get("RT_DEPTHS", "0,2,4,8").split(",") if x] + \
+        [("frame batch", int(x)) for x in os.environ.get("RT_BATCHES", "4,8,16,32").split(",") if x]
+for mode, depth in MODES:
     r = HipRenderer(0); r.upload(sc)
-    r.set_frame_pipelining(depth)
+    if mode == "frame batch":
+        r.set_frame_batch(depth)
+    else:
+        r.set_frame_pipelining(depth)
     r.render(W, H, 1, 2, 50, 1, stats=False); r.synchronize()   # warm-up (buffers, LDS attribute)
     best = None
     for rep in range(3):
@@ -27,6 +32,6 @@ for depth in [int(x) for x in os.environ.get("RT_DEPTHS", "0,2,4,8").split(",")]
         dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
     r.resolve(); hdr, _ = r.download()
-    print("pipelining depth %d: %d frames of 1 spp: %.3f ms per frame (%.3f ms host enqueue), %.0f Msamples/s, == one shot: %s"
-          % (depth, N, best / N * 1e3, t_enqueue / N * 1e3, W * H * N / best / 1e6, np.array_equal(hdr.view(np.uint32), h1.view(np.uint32))), flush=True)
+    print("%s %d: %d frames of 1 spp: %.3f ms per frame (%.3f ms host enqueue), %.0f Msamples/s, == one shot: %s"
+          % (mode, depth, N, best / N * 1e3, t_enqueue / N * 1e3, W * H * N / best / 1e6, np.array_equal(hdr.view(np.uint32), h1.view(np.uint32))), flush=True)
     r.close()
