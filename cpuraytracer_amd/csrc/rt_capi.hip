@@ -808,12 +808,27 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     // Hit stash (rt_kernels.h, kStash): the matrix-core variants at 1024 threads regroup their hit processing through a per-wave
     // stash of up to 63 hit records in the room the path cache would take -- as many records as the LDS left over holds
     // (RT_STASH=0: the path-cache variants; RT_STASH_CAP: fewer records).  depth shares its register with the scan entry.
-    bool useStash = false;
+    bool useStash = false, matsL2 = false;
     {
-        const size_t room = 160 * 1024 / ctx->blocksPerCu > ldsBytes ? (160 * 1024 / ctx->blocksPerCu - ldsBytes) / wavesPerBlock / 16 * 16 : 0;
+        size_t room = 160 * 1024 / ctx->blocksPerCu > ldsBytes ? (160 * 1024 / ctx->blocksPerCu - ldsBytes) / wavesPerBlock / 16 * 16 : 0;
         uint32_t cap = (uint32_t)(room / (rtd::kStashDwords * 4));
-        cap = cap > 63u ? 63u : cap;
         const uint32_t capEnv = EnvU32("RT_STASH_CAP", 63u);
+        // Flat variant: when the material table's 48 bytes per sphere would buy at least eight more records per wave, the
+        // materials are read through L2 instead (kMatsL2; measured on the cover scene: 44 -> 63 records, +1 %; RT_MATS_L2=0: never)
+        if (flat && tp.mats_in_lds && (sgBytes != 0 || !tp.sg_enabled) && cap < 63u && cap < capEnv && EnvU32("RT_MATS_L2", 1u) != 0u && ctx->useStash &&
+            carryMode == 0 && ctx->blockThreads == 1024 && tp.max_depth < 65536u) {  // (exactly when the stash variant will be launched)
+            const size_t matBytes = (size_t)tp.n_padded * 48;
+            const size_t room2 = (160 * 1024 / ctx->blocksPerCu - (ldsBytes - matBytes)) / wavesPerBlock / 16 * 16;
+            uint32_t cap2 = (uint32_t)(room2 / (rtd::kStashDwords * 4));
+            cap2 = cap2 > 63u ? 63u : cap2;
+            if (cap2 >= cap + 8u) {
+                matsL2 = true;
+                ldsBytes -= matBytes;
+                room = room2;
+                cap = cap2;
+            }
+        }
+        cap = cap > 63u ? 63u : cap;
         cap = cap > capEnv ? capEnv : cap;
         if (ctx->useStash && carryMode == 0 && (flat || tree || grid) && ctx->blockThreads == 1024 && tp.max_depth < 65536u && cap >= 16u) {
             useStash = true;
@@ -876,6 +891,7 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     else if (grid) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 256, 3, true, false>));
     else if (useStash && tree && tp.tree_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 2, true, true, false, true>));
     else if (useStash && tree) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 2, true, false, false, true>));
+    else if (useStash && hitLds && matsL2) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 1, true, true, false, true, true>));
     else if (useStash && hitLds) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 1, true, true, false, true>));
     else if (useStash) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 1, true, false, false, true>));
     else if (tree) RT_LAUNCH_T(false, 2);

@@ -109,7 +109,9 @@ struct SceneTabs {
 // levels of bounds are in LDS.  Their pointers are assigned unconditionally so that the compiler can prove the address space -- a pointer that is LDS or global
 // depending on a run-time flag becomes a FLAT load, and every flat load waits for vmcnt(0) AND lgkmcnt(0), i.e. also
 // for the previous iteration's sample stores.  The host launches it only when p.mats_in_lds and (p.sg_in_lds or no index).
-template <bool kLds, int kScan, bool kHitLds = false>
+// kMatsL2 (with kHitLds): the material table is NOT staged -- it is read through L2 with a global-address-space pointer, and
+// the 48 bytes per sphere it would take go to the hit stash (on the cover scene 44 -> 63 records per wave).
+template <bool kLds, int kScan, bool kHitLds = false, bool kMatsL2 = false>
 RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
     constexpr bool kMfma = kScan == 1 || kScan == 2;
     T.gridCells = p.grid_cell_start;
@@ -134,7 +136,7 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
         constexpr bool kLeafLds = kScan == 1 || kScan == 3;  // the scans that test one-sphere bounds from LDS
         uint32_t* ldsOrig = reinterpret_cast<uint32_t*>(ldsLeaf + (kLeafLds ? p.n_padded : 0u));
         float4* ldsMat = reinterpret_cast<float4*>(ldsOrig + p.n_padded);  // n_padded is a multiple of 4
-        const uint32_t nMatLds = (kHitLds || p.mats_in_lds) ? p.n_padded : 0u;
+        const uint32_t nMatLds = kMatsL2 ? 0u : ((kHitLds || p.mats_in_lds) ? p.n_padded : 0u);
         float* ldsRad = reinterpret_cast<float*>(ldsMat + (size_t)nMatLds * 3);
         const float4* gMat = reinterpret_cast<const float4*>(p.mats);
         for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) {
@@ -193,7 +195,8 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
         T.orig = ldsOrig;
         if (kLeafLds) T.leaf = ldsLeaf;
         T.rad = ldsRad;
-        if (kHitLds) T.mats = reinterpret_cast<const rt_material*>(ldsMat);
+        if (kMatsL2) T.mats = p.mats;  // (a kernel argument: global address space, no flat loads)
+        else if (kHitLds) T.mats = reinterpret_cast<const rt_material*>(ldsMat);
         else if (p.mats_in_lds) T.mats = reinterpret_cast<const rt_material*>(ldsMat);
     } else if (kScan == 3) {
         // cell-grid scan: the exact tables stay in global memory (L2); the cells' first entries live in LDS (kHitLds: typed pointer)
@@ -277,8 +280,9 @@ RT_DEV bool claim_block(const TraceParams& p, SceneConsts* ldsK, uint32_t lane, 
 // 64 fresh paths straight into registers, scan, and the lanes that missed pop stashed hits until the wave is full of
 // hits.  Scans run with ~59 live rays, hit processing with ~58 lanes instead of 36.  Every path sees the same sequence of
 // operations on the same values as before: only WHEN a hit is processed changes, never what is computed.
-template <bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds = false, bool kCarry = false, bool kStash = false>
+template <bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds = false, bool kCarry = false, bool kStash = false, bool kMatsL2 = false>
 __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams p) {
+    static_assert(!kMatsL2 || (kHitLds && kStash && kLds), "materials through L2: a flavour of the all-in-LDS stash variants");
     constexpr bool kMfma = kScan == 1 || kScan == 2;  // matrix-core filter; kScan == 3: cell-grid scan (rt_scan.h scan_list_grid)
     static_assert(!kCarry || (kCache && kHitLds && kScan == 1), "frame pipelining is built for the flat LDS variant only");
     static_assert(!kStash || (kCache && !kCarry), "the hit stash takes the LDS region of the prepared-path cache");
@@ -307,7 +311,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     constexpr uint32_t kWaveRegion = kScan >= 2 ? kWaveCandBytes : kWaveListBytes;  // the work lists of the hierarchy and grid scans
     float4* tabBase = smem + kConstBytes / 16 + (kThreads / kWaveSize) * (kWaveRegion / 16);
     SceneTabs T;
-    stage_scene<kLds, kScan, kHitLds>(p, tabBase, T);  // ends with a workgroup barrier when it staged anything
+    stage_scene<kLds, kScan, kHitLds, kMatsL2>(p, tabBase, T);  // ends with a workgroup barrier when it staged anything
     const float4* scanTab = T.scan;
     const uint32_t* origTab = T.orig;
     const float4* leafTab = T.leaf;

@@ -892,6 +892,7 @@ def _render_with_env(monkeypatch, env, sc, W, H, s1, depth=50, seed=1):
     {"RT_STASH": "0"},                                         # the prepared-path cache variants instead of the hit stash
     {"RT_STASH": "0", "RT_RAY_CACHE": "0"},                    # neither: idle lanes generate their own paths
     {"RT_STASH_CAP": "16"}, {"RT_STASH_CAP": "63"},            # smallest and largest stash
+    {"RT_MATS_L2": "0"},                                       # the material table in LDS and a smaller stash (default: through L2)
     {"RT_GRID": "2"},                                          # the cell-grid scan (tables in LDS) instead of the matrix-core filter
     {"RT_GRID": "2", "RT_MATS_LDS": "0"},                      # ... with its tables through L2
     {"RT_GRID": "2", "RT_STASH": "0", "RT_SHADOW_GRID": "0"},
@@ -1061,6 +1062,22 @@ def test_error_codes(hip, scenes_mod):
     with pytest.raises(RtError):
         HipRenderer(4096)
     r.close()
+
+
+def test_depth_limits_beyond_the_stash_records_range_take_the_cache_variant(hip, oracle, scenes_mod):
+    """The hit stash keeps the depth beside the scan entry in one 32-bit field; a depth limit of 65,536 or more (the reference
+    uses 50) selects the prepared-path-cache variant instead, with the same results."""
+    sc = scenes_mod.build_scene("cover", 1, 96, 64)
+    hip.upload(sc)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    for depth in (65535, 70000):
+        sg = hip.render(96, 64, 1, 3, depth, 5)
+        hg, _ = hip.download(ldr=False)
+        so = orc.render(96, 64, 1, 3, depth, 5, accel=oracle.ACCEL_PADDED_LIST, threads=8)
+        ho, _ = orc.download()
+        assert_same(hg, ho, "HDR at depth limit %d" % depth)
+        assert (sg.traversals, sg.segments) == (so.traversals, so.segments)
 
 
 def test_scene_size_limit_is_an_error_not_a_truncation(hip, oracle):
