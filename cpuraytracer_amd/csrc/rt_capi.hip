@@ -833,6 +833,8 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
         if (ctx->useStash && carryMode == 0 && (flat || tree || grid) && ctx->blockThreads == 1024 && tp.max_depth < 65536u && cap >= 16u) {
             useStash = true;
             tp.stash_cap = cap;
+            const uint32_t procEnv = EnvU32("RT_STASH_PROCESS", 63u);  // experiments: process hits from this many + 1 lanes on
+            tp.stash_process = procEnv < cap ? procEnv : cap;
             tp.ray_cache_off16 = (uint32_t)(ldsBytes / 16);
             tp.ray_cache_stride16 = (cap * rtd::kStashDwords * 4 + 15) / 16;
             ldsBytes += (size_t)wavesPerBlock * tp.ray_cache_stride16 * 16;

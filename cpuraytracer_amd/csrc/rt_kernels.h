@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
             // (2) process the hits when (nearly) every lane holds one; with fewer and nothing to scan, make room for 64 fresh paths
             const uint64_t hitMask = __ballot(state == kHaveHit);
             const uint32_t nHit = (uint32_t)__popcll(hitMask);
-            bool process = nHit > cap;
+            bool process = nHit > p.stash_process;
             if (!process && nHit != 0u && __ballot(state == kNeedClosest || state == kNeedShadow) == 0ull) {
                 if (blkNext == blkEnd && !queueEmpty && !nextBlock()) queueEmpty = true;
                 if (blkNext == blkEnd) {

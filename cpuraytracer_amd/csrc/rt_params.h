@@ -180,8 +180,9 @@ struct TraceParams {
     FastDiv fd_tile, fd_w, fd_rows;  // division by 64 * spp_pass, W and rs.block_rows (set per launch)
     uint32_t ray_cache_off16;  // float4 offset of the per-wave prepared-path caches (or hit stashes) in dynamic LDS, 0 = none
     uint32_t ray_cache_stride16;  // ... and the size of one wave's region in float4
-    uint32_t stash_cap;        // kStash variants (rt_kernels.h): records a wave's hit stash holds (<= 63); hits are processed
-                               // once more than this many lanes hold one
+    uint32_t stash_cap;        // kStash variants (rt_kernels.h): records a wave's hit stash holds (<= 63)
+    uint32_t stash_process;    // ... hits are processed once MORE than this many lanes hold one (<= stash_cap: what is not
+                               // processed must fit the stash)
     uint32_t* shard_heads;      // [kQueueShards][kShardStrideWords]: [k][0] = cursor of queue shard k (blocks claimed from it; zeroed before launch)
     unsigned long long* counters;  // [0] traversals, [1] segments
 };
