@@ -799,6 +799,19 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     size_t gridBytes = (grid && ctx->blockThreads == 1024) ? (((size_t)tp.grid_nu * tp.grid_nv + 1) * 2 + 15) / 16 * 16 : 0;
     if (candBytes + gridBytes > 160 * 1024) gridBytes = 0;  // (cannot happen below 60,000 cells)
     tp.grid_in_lds = gridBytes ? 1u : 0u;
+    // cell-grid scan with its tables in global memory, RT_GRID_SG_LDS=1 (experiments): the shadow index in LDS next to the cells when
+    // that leaves a stash of at least 24 records.  Measured on grid10k: 48.6 KB of index leave 31 records instead of 63: -5 %
+    // (6.47 vs 6.82 Gsamples/s) -- the full stash is worth more than the three dependent L2 reads per shadow query it would save.
+    bool gridSgLds = false;
+    if (grid && !gridLds && gridBytes != 0 && tp.sg_enabled && ctx->useStash && carryMode == 0 && ctx->blockThreads == 1024 && tp.max_depth < 65536u &&
+        EnvU32("RT_GRID_SG_LDS", 0u) != 0u) {
+        const size_t sgb = (((size_t)tp.sg_nx * tp.sg_ny + 1 + tp.sg_nentries + tp.sg_nglobal) * 2 + 15) / 16 * 16;
+        const size_t used = candBytes + gridBytes + sgb;
+        if (used + (size_t)wavesPerBlock * 24 * rtd::kStashDwords * 4 + 256 <= 160 * 1024) {
+            gridSgLds = true;
+            sgBytes = sgb;
+        }
+    }
     size_t ldsBytes = candBytes + ((ldsTables || gridLds) ? lds : 0) + ((flat || gridLds) ? leafBytes : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0) + sgBytes + treeBytes + gridBytes;
     // per-wave caches of prepared paths go last, when there is room left (RT_RAY_CACHE=0 disables them)
     ldsBytes = (ldsBytes + 15) / 16 * 16;
@@ -883,6 +896,8 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     else if (gridLds && useStash && tp.grid_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 3, true, true, false, true>));
     else if (gridLds && tp.grid_in_lds && tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 3, true, true>));
     else if (gridLds && tp.grid_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 3, false, true>));
+    else if (grid && gridSgLds && useStash && tp.grid_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 3, true, true, false, true, false, true>));
+    else if (grid && gridSgLds) return Fail(RT_ERR_HIP, "internal: the grid variant with the shadow index in LDS needs the hit stash");
     else if (grid && ctx->blockThreads == 1024 && useStash && tp.grid_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 3, true, true, false, true>));
     else if (grid && ctx->blockThreads == 1024 && tp.grid_in_lds && tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 3, true, true>));
     else if (grid && ctx->blockThreads == 1024 && tp.grid_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 3, false, true>));

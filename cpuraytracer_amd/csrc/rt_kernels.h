@@ -111,7 +111,8 @@ struct SceneTabs {
 // for the previous iteration's sample stores.  The host launches it only when p.mats_in_lds and (p.sg_in_lds or no index).
 // kMatsL2 (with kHitLds): the material table is NOT staged -- it is read through L2 with a global-address-space pointer, and
 // the 48 bytes per sphere it would take go to the hit stash (on the cover scene 44 -> 63 records per wave).
-template <bool kLds, int kScan, bool kHitLds = false, bool kMatsL2 = false>
+// kSgLds (cell-grid scan with its tables in global memory): the shadow index is staged behind the cells (typed LDS pointers).
+template <bool kLds, int kScan, bool kHitLds = false, bool kMatsL2 = false, bool kSgLds = false>
 RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
     constexpr bool kMfma = kScan == 1 || kScan == 2;
     T.gridCells = p.grid_cell_start;
@@ -202,9 +203,19 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
         // cell-grid scan: the exact tables stay in global memory (L2); the cells' first entries live in LDS (kHitLds: typed pointer)
         if (kHitLds) {
             uint16_t* g = reinterpret_cast<uint16_t*>(tabBase);
-            const uint32_t nc = p.grid_nu * p.grid_nv + 1u;
-            for (uint32_t k = threadIdx.x; k < nc; k += blockDim.x) g[k] = p.grid_cell_start[k];
+            const uint32_t ng = p.grid_nu * p.grid_nv + 1u;
+            for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) g[k] = p.grid_cell_start[k];
             T.gridCells = g;
+            if (kSgLds) {  // the shadow index behind the cells (16-byte steps); the host launches this flavour only when the scene has one
+                uint16_t* sgl = g + ((ng + 7u) & ~7u);
+                const uint32_t nc = p.sg_nx * p.sg_ny + 1u;
+                for (uint32_t k = threadIdx.x; k < nc; k += blockDim.x) sgl[k] = p.sg_cell_start[k];
+                for (uint32_t k = threadIdx.x; k < p.sg_nentries; k += blockDim.x) sgl[nc + k] = p.sg_entries[k];
+                for (uint32_t k = threadIdx.x; k < p.sg_nglobal; k += blockDim.x) sgl[nc + p.sg_nentries + k] = p.sg_global[k];
+                T.sgCell = sgl;
+                T.sgEntries = sgl + nc;
+                T.sgGlobal = sgl + nc + p.sg_nentries;
+            }
             __syncthreads();
         }
     } else if (kMfma) {
@@ -280,8 +291,10 @@ RT_DEV bool claim_block(const TraceParams& p, SceneConsts* ldsK, uint32_t lane, 
 // 64 fresh paths straight into registers, scan, and the lanes that missed pop stashed hits until the wave is full of
 // hits.  Scans run with ~59 live rays, hit processing with ~58 lanes instead of 36.  Every path sees the same sequence of
 // operations on the same values as before: only WHEN a hit is processed changes, never what is computed.
-template <bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds = false, bool kCarry = false, bool kStash = false, bool kMatsL2 = false>
+template <bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds = false, bool kCarry = false, bool kStash = false, bool kMatsL2 = false,
+          bool kSgLds = false>
 __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams p) {
+    static_assert(!kSgLds || (kScan == 3 && !kLds && kHitLds), "shadow index in LDS next to the grid's cells: the global-tables grid variant");
     static_assert(!kMatsL2 || (kHitLds && kStash && kLds), "materials through L2: a flavour of the all-in-LDS stash variants");
     constexpr bool kMfma = kScan == 1 || kScan == 2;  // matrix-core filter; kScan == 3: cell-grid scan (rt_scan.h scan_list_grid)
     static_assert(!kCarry || (kCache && kHitLds && kScan == 1), "frame pipelining is built for the flat LDS variant only");
@@ -311,7 +324,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     constexpr uint32_t kWaveRegion = kScan >= 2 ? kWaveCandBytes : kWaveListBytes;  // the work lists of the hierarchy and grid scans
     float4* tabBase = smem + kConstBytes / 16 + (kThreads / kWaveSize) * (kWaveRegion / 16);
     SceneTabs T;
-    stage_scene<kLds, kScan, kHitLds, kMatsL2>(p, tabBase, T);  // ends with a workgroup barrier when it staged anything
+    stage_scene<kLds, kScan, kHitLds, kMatsL2, kSgLds>(p, tabBase, T);  // ends with a workgroup barrier when it staged anything
     const float4* scanTab = T.scan;
     const uint32_t* origTab = T.orig;
     const float4* leafTab = T.leaf;
