@@ -1,7 +1,8 @@
 """Model of the hit-stash control flow of rt_trace_kernel (kStash variants, rt_kernels.h): one wave, 64 lanes, the same steps
 in the same order — stash step (pop, decide, push or process), fresh paths when every lane is idle, exit check, scan,
 transitions — with random scan and hit-processing outcomes.  Checked for every parameter set, adversarial ones included
-(every scan hits and every hit ends its path: the case in which the first version left the loop with records in the stash):
+(every hit ends its path while only part of the scans hit: the case in which the first version left the loop with records
+in the stash — with `break` in place of `continue` below, four of these parameter sets fail):
 
   * the loop ends, and only when every lane is idle, the stash is empty and the queue is drained;
   * every path handed out is finished exactly once (no record lost, none processed twice);
@@ -111,7 +112,7 @@ def run_wave(cap, n_paths, block, p_hit, p_finish, p_far, seed, max_iters=200000
 
 @pytest.mark.parametrize("cap", [16, 31, 44, 63])
 @pytest.mark.parametrize("p_hit,p_finish,p_far", [(0.59, 0.06, 0.0), (1.0, 1.0, 0.0), (1.0, 0.0, 0.0), (0.0, 0.5, 0.0), (0.59, 0.06, 0.3),
-                                                  (0.95, 0.5, 1.0), (0.3, 0.9, 0.05)])
+                                                  (0.95, 0.5, 1.0), (0.3, 0.9, 0.05), (0.7, 1.0, 0.0), (0.85, 1.0, 0.0), (0.5, 1.0, 0.0)])
 def test_a_wave_finishes_every_path_once_and_leaves_with_an_empty_stash(cap, p_hit, p_finish, p_far):
     for seed, (n_paths, block) in enumerate([(128, 128), (3 * 256 + 51, 256), (64, 128), (1, 128), (1000, 128)]):
         if p_hit == 1.0 and p_finish == 0.0:
