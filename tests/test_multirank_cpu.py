@@ -56,7 +56,7 @@ def _worker(rank, world, port, H, W, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,H", [(2, 48), (2, 50), (3, 50)])
+@pytest.mark.parametrize("world,H", [(2, 48), (2, 50), (3, 50), (4, 50), (8, 96)])
 def test_sharded_render_gathers_to_the_single_rank_image(built, oracle, tmp_path, world, H):
     import torch.multiprocessing as mp
     W = 64
