@@ -852,6 +852,13 @@ struct GridParams {
     float rmaxOverH;            // largest radius among the grid's spheres, in cells
     float bigNorm;              // max |c| + r over the big spheres (the scale of their bounds' behind-the-origin threshold)
 };
+#ifndef RT_GRID_DRAIN
+#define RT_GRID_DRAIN 32
+#endif
+// exact entries that trigger a drain in the grid scan: the walk is front to back, so early hits end it early -- measured on
+// grid10k: 128 (the hierarchy's value) -> 64 +1.5 %, 48 +2.3 %, 32 +3.5 %
+constexpr uint32_t kGridDrain = RT_GRID_DRAIN;
+static_assert(kTreeExact >= kGridDrain + 4 * 64, "a step may add 256 entries to an exact list that holds up to kGridDrain - 1");
 constexpr float kGridSlack = 1e-3f;  // cells: >= 40 x the rounding of a grid coordinate (|coordinate| <= 256 cells, 2^-24 relative)
 
 // The v-range (rows) of slab iu for a segment S -> E in grid coordinates, widened by D: rows [r0, r1] clamped to the grid, or
@@ -1019,11 +1026,11 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
             const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             uint32_t* wp = work + nWork + (incl - cnt);
             for (uint32_t k = 0; k < cnt; ++k) wp[k] = lane << 8 | (uint32_t)(slab + (int)k * slabStep);
+            nWork += tot;
             if (cnt != 0u) {
                 if ((uint32_t)((slabLast - slab) * slabStep) + 1u == cnt) pending = false;
                 slab += (int)cnt * slabStep;
             }
-            nWork += tot;
         }
         if (nWork == 0u) break;
         wave_lds_handoff();  // items listed by other lanes
@@ -1065,7 +1072,7 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
                     rb = __builtin_amdgcn_alignbit(rb, (uint32_t)rej, 31);
                 }
                 const uint32_t m = ~rb & 15u;  // bit 3-q = entry eb + q
-                if (nExact >= kFarDrain) drainExact();  // early and often: every exact round may pull the far limits in
+                if (nExact >= kGridDrain) drainExact();  // early and often: every exact round may pull the far limits in
                 {
                     const uint32_t nh = (uint32_t)__builtin_popcount(m);
                     const uint32_t incl = wave_inclusive_sum(nh);
