@@ -502,6 +502,51 @@ def test_hits_left_in_the_stash_when_every_lane_finishes_are_not_lost(hip, oracl
     _assert_image_equals_oracle(hip, oracle, sc, W, H, spp, 12, seed=5)
 
 
+def _layer_scene(oracle, rng, n, side, cam_o, cam_l, vfov=40.0, plane="xz", clump=0, n_big=0, r_small=0.2):
+    """n small spheres in a layer (plus a floor): the scene class of the cell-grid scan, with the knobs that stress it."""
+    a, b = rng.uniform(-side, side, n), rng.uniform(-side, side, n)
+    if clump:
+        a[:clump], b[:clump] = rng.uniform(-1.5, 1.5, clump), rng.uniform(-1.5, 1.5, clump)
+    h = np.full(n, r_small) + rng.uniform(0, 0.05, n)
+    c = np.stack([a, h, b], 1) if plane == "xz" else np.stack([a, b + side + 1.0, h], 1)
+    r_ = np.full(n, r_small) * rng.uniform(0.5, 1.0, n)
+    t = rng.choice([0, 0, 0, 1, 2, 3], n)
+    c = np.concatenate([c, [[0.0, -1000.0, 0.0]]])
+    r_ = np.concatenate([r_, [1000.0]])
+    t = np.concatenate([t, [0]])
+    for k in range(n_big):
+        c = np.concatenate([c, [[rng.uniform(-side, side), 3.0, rng.uniform(-side, side)]]])
+        r_ = np.concatenate([r_, [3.0]])
+        t = np.concatenate([t, [rng.choice([0, 1, 2])]])
+    sc = _custom_scene(oracle, c.astype(np.float32), r_.astype(np.float32), t.astype(np.uint32), cam_o, cam_l, vfov, 1.5)
+    sc.materials["luminance"] = np.where(sc.materials["type"] == 3, 3000.0, 0.0).astype(np.float32)
+    return sc
+
+
+@pytest.mark.parametrize("case", ["grazing", "far_camera", "wall", "clumped", "nine_big", "inside_layer", "tiny_spheres"])
+def test_cell_grid_scan_stress_scenes_equal_the_oracle(hip, oracle, case):
+    """Scenes built against the cell-grid scan's weak spots, as whole images vs the oracle's list semantics: rays that skim the
+    whole layer (hundreds of slabs per ray), a camera thousands of units away (the per-ray reach, hence the walk's dilation, grows
+    with |o|), a layer in a vertical plane (another thin axis), 1,500 spheres clumped into a few cells (runs of hundreds of entries
+    per item), nine big spheres (the grid builder refuses: bounds hierarchy), a camera inside the layer, spheres of 2 cm."""
+    rng = np.random.default_rng({"grazing": 1, "far_camera": 2, "wall": 3, "clumped": 4, "nine_big": 5, "inside_layer": 6, "tiny_spheres": 7}[case])
+    if case == "grazing":
+        sc = _layer_scene(oracle, rng, 4000, 60.0, (70.0, 0.25, 0.3), (-60.0, 0.2, 0.0), vfov=20.0)
+    elif case == "far_camera":
+        sc = _layer_scene(oracle, rng, 3000, 40.0, (2500.0, 900.0, -1800.0), (0.0, 0.0, 0.0), vfov=2.5)
+    elif case == "wall":
+        sc = _layer_scene(oracle, rng, 2500, 30.0, (5.0, 35.0, -60.0), (0.0, 31.0, 0.0), plane="xy")
+    elif case == "clumped":
+        sc = _layer_scene(oracle, rng, 2000, 100.0, (6.0, 3.0, -6.0), (0.0, 0.2, 0.0), clump=1500)
+    elif case == "nine_big":
+        sc = _layer_scene(oracle, rng, 2000, 30.0, (35.0, 8.0, -20.0), (0.0, 1.0, 0.0), n_big=9)
+    elif case == "inside_layer":
+        sc = _layer_scene(oracle, rng, 5000, 50.0, (0.37, 0.21, 0.41), (20.0, 0.2, 3.0), vfov=80.0)
+    else:
+        sc = _layer_scene(oracle, rng, 6000, 3.0, (4.0, 0.6, -3.0), (0.0, 0.02, 0.0), r_small=0.02)
+    _assert_image_equals_oracle(hip, oracle, sc, 192, 128, 2, 20, seed=11)
+
+
 # ------------------------------------------- properties at BASELINE.json's full size (C2)
 @pytest.fixture(scope="module")
 def c2_full(hip, scenes_mod):
