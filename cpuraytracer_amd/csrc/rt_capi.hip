@@ -403,6 +403,19 @@ static bool BuildGridLayout(const rt_sphere* sp, uint32_t n, const std::vector<u
         keyed.push_back({iu * nv + iv, k});
     }
     std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
+    {   // a uniform grid suits a uniform layer: when the spheres are clumped (the average sphere shares its cell with more than
+        // five others; a Poisson layer at one sphere per cell has one) a ray through a clump would test hundreds of spheres per
+        // cell -- measured 3x slower than the bounds hierarchy on 1,500 spheres in a 3 x 3 patch of a 200 x 200 layer -- so the
+        // hierarchy takes such scenes
+        double sumSq = 0.0;
+        for (size_t q = 0; q < keyed.size();) {
+            size_t e = q;
+            while (e < keyed.size() && keyed[e].first == keyed[q].first) ++e;
+            sumSq += (double)(e - q) * (double)(e - q);
+            q = e;
+        }
+        if (sumSq / (double)keyed.size() > 6.0) return false;
+    }
     std::vector<std::vector<uint32_t>> groups;
     for (uint32_t k : big) groups.push_back({k});
     while (groups.size() & 3u) groups.push_back({});
@@ -1910,6 +1923,18 @@ int rt_unit_layout(const rt_sphere* spheres, uint32_t n, uint32_t cap_groups, ui
     if (cap_groups < L.nGroups || !orig || !bounds) return Fail(RT_ERR_INVALID_ARG, "rt_unit_layout: capacity too small");
     std::memcpy(orig, L.orig.data(), (size_t)L.nGroups * 4 * sizeof(uint32_t));
     std::memcpy(bounds, L.tree.data(), (size_t)L.nGroups * sizeof(float4));  // level 0 comes first
+    return RT_OK;
+}
+
+int rt_unit_layout_info(const rt_sphere* spheres, uint32_t n, uint32_t out[5]) {
+    if (!spheres || n == 0 || !out) return Fail(RT_ERR_INVALID_ARG, "rt_unit_layout_info: invalid argument");
+    SceneLayout L;
+    BuildLayout(spheres, n, 128, L);
+    out[0] = L.gridOn ? 1u : (L.nLevels > 1 ? 2u : 0u);
+    out[1] = L.gridOn ? L.gridNu : 0u;
+    out[2] = L.gridOn ? L.gridNv : 0u;
+    out[3] = L.nAlways;
+    out[4] = L.nLevels;
     return RT_OK;
 }
 

@@ -253,6 +253,10 @@ int rt_unit_scatter(rt_ctx* ctx, const rt_material* material, const rt_light* su
  * conservative bounding sphere each).  orig: 4 entries per group, 0xffffffff = padding;
  * bounds: Cx, Cy, Cz, |C|^2 - Rf^2 per group.  cap_groups == 0 only queries *n_groups.  Needs no GPU. */
 int rt_unit_layout(const rt_sphere* spheres, uint32_t n, uint32_t cap_groups, uint32_t* n_groups, uint32_t* orig, float* bounds);
+/* ... and which closest-hit scan that storage is laid out for: out[0] = 0 flat matrix-core filter (<= 128 groups), 1 cell grid,
+ * 2 bounds hierarchy; out[1], out[2] = grid cells along its two axes (0 otherwise); out[3] = big spheres tested for every ray;
+ * out[4] = levels of bounds.  Needs no GPU. */
+int rt_unit_layout_info(const rt_sphere* spheres, uint32_t n, uint32_t out[5]);
 /* The resolve of spheres-app.cpp:196-214 for given HDR triples -> R,G,B bytes */
 int rt_unit_tonemap(rt_ctx* ctx, const float* hdr_rgb, uint32_t n, uint32_t n_samples, uint8_t* out_rgb);
 

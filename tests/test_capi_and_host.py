@@ -173,3 +173,36 @@ def test_invariant_division_by_multiplication_is_exact():
         q = ((t + ((n - t) >> np.uint64(s1))) & np.uint64(0xffffffff)) >> np.uint64(s2)
         # (t + ((n - t) >> s1)) never exceeds 32 bits for a valid magic: the mask only documents the register width
         assert np.array_equal(q, n // np.uint64(d)), d
+
+
+def test_which_scan_a_scene_is_laid_out_for(built, oracle):
+    """rt_scene_upload's choice of closest-hit scan (host logic, no GPU): the cover scene fits the flat matrix-core filter; the
+    10,004-sphere layer gets the cell grid (about one sphere per cell, the four big spheres tested for every ray); a layer whose
+    spheres are clumped, or a scene with more than eight big spheres, goes to the bounds hierarchy."""
+    from cpuraytracer_amd import _capi
+    L = _capi.load()
+
+    def info(spheres):
+        sph = np.ascontiguousarray(spheres)
+        out = (C.c_uint32 * 5)()
+        _capi.check(L.rt_unit_layout_info(sph.ctypes.data, sph.shape[0], out))
+        return list(out)
+    assert info(oracle.build_scene("cover", 1, 1.5).spheres)[0] == 0
+    assert info(oracle.build_scene("three", 1, 2.0).spheres)[0] == 0
+    g = info(oracle.build_scene("grid10k", 1, 1.0).spheres)
+    assert g[0] == 1 and g[3] == 4 and 0.6 * 10000 <= g[1] * g[2] <= 1.6 * 10000 and g[4] == 1
+    rng = np.random.default_rng(4)
+
+    def layer(n, side, clump=0, n_big=0):
+        sph = np.zeros(n + 1 + n_big, dtype=oracle.SPHERE_DTYPE)
+        a, b = rng.uniform(-side, side, n), rng.uniform(-side, side, n)
+        a[:clump], b[:clump] = rng.uniform(-1.5, 1.5, clump), rng.uniform(-1.5, 1.5, clump)
+        sph["cx"][:n], sph["cy"][:n], sph["cz"][:n], sph["r"][:n] = a, 0.2, b, 0.2
+        sph["cy"][n], sph["r"][n] = -1000.0, 1000.0
+        for k in range(n_big):
+            sph[n + 1 + k] = (rng.uniform(-side, side), 3.0, rng.uniform(-side, side), 3.0)
+        return sph
+    assert info(layer(2000, 30.0))[0] == 1
+    assert info(layer(2000, 100.0, clump=1500))[0] == 2   # clumped: the average sphere shares its cell with many others
+    assert info(layer(2000, 30.0, n_big=9))[0] == 2       # ten big spheres with the floor: more than the every-ray list takes
+    assert info(layer(300, 10.0))[0] == 0                 # 76 groups: the flat filter
