@@ -863,26 +863,32 @@ constexpr float kGridSlack = 1e-3f;  // cells: >= 40 x the rounding of a grid co
 
 // The v-range (rows) of slab iu for a segment S -> E in grid coordinates, widened by D: rows [r0, r1] clamped to the grid, or
 // r0 > r1 when the slab is not within D of the segment.  Also the segment parameter s in [0, 1] at which the walk enters the slab.
-RT_DEV void grid_slab_rows(float su, float sv, float eu, float ev, float D, int iu, int nv, int& r0, int& r1, float& sEnter) {
+// slope = dv/du and invAbsDu = 1/|du| of the segment, once per ray (grid_segment_slope); invAbsDu == 0: the segment is (nearly)
+// parallel to v.
+RT_DEV void grid_segment_slope(float su, float sv, float eu, float ev, float& slope, float& invAbsDu) {
     const float du = eu - su, dv = ev - sv;
+    const bool steep = __builtin_fabsf(du) < 1e-4f * __builtin_fmaxf(__builtin_fabsf(dv), 1.f);
+    slope = steep ? 0.f : dv / du;
+    invAbsDu = steep ? 0.f : 1.f / __builtin_fabsf(du);
+}
+RT_DEV void grid_slab_rows(float su, float sv, float eu, float ev, float D, float slope, float invAbsDu, int iu, int nv, int& r0, int& r1,
+                           float& sEnter) {
     const float ulo = __builtin_fminf(su, eu), uhi = __builtin_fmaxf(su, eu);
     // the part of the segment whose u lies within D of the slab [iu, iu + 1]
     const float a = __builtin_fmaxf(ulo, (float)iu - D - kGridSlack), b = __builtin_fminf(uhi, (float)(iu + 1) + D + kGridSlack);
     float vlo, vhi;
-    const bool steep = __builtin_fabsf(du) < 1e-4f * __builtin_fmaxf(__builtin_fabsf(dv), 1.f);
-    if (steep) {  // (nearly) parallel to v: the whole v-extent of the segment
+    if (invAbsDu == 0.f) {  // (nearly) parallel to v: the whole v-extent of the segment
         vlo = __builtin_fminf(sv, ev);
         vhi = __builtin_fmaxf(sv, ev);
         sEnter = 0.f;
     } else {
-        const float slope = dv / du;
         const float va = __builtin_fmaf(a - su, slope, sv), vb = __builtin_fmaf(b - su, slope, sv);
         const float pad = 1e-4f * __builtin_fabsf(slope);  // (u - su) is good to 4e-5 cells; times the slope
         vlo = __builtin_fminf(va, vb) - pad;
         vhi = __builtin_fmaxf(va, vb) + pad;
-        const float uNear = du > 0.f ? a : b;  // where the walk direction enters the slab's neighbourhood ...
-        // ... moved a slack towards the start; as a fraction of the segment
-        sEnter = __builtin_fminf(__builtin_fmaxf((__builtin_fabsf(uNear - su) - kGridSlack) / __builtin_fabsf(du), 0.f), 1.f);
+        const float uNear = eu > su ? a : b;  // where the walk direction enters the slab's neighbourhood ...
+        // ... moved a slack towards the start; as a fraction of the segment (rounded down by more than the product's rounding)
+        sEnter = __builtin_fminf(__builtin_fmaxf((__builtin_fabsf(uNear - su) - kGridSlack) * invAbsDu * (1.f - 0x1p-20f), 0.f), 1.f);
     }
     if (a > b) {  // the slab is farther than D from the segment
         r0 = 1;
@@ -916,7 +922,7 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
     uint32_t nWork = 0, nExact = 0;
     // the ray clipped to the padded box of the grid's spheres (the derivation is the hierarchy scan's, above)
     float boxUn = -__builtin_inff(), boxUf = __builtin_inff();
-    float su = 0.f, sv = 0.f, eu = 0.f, ev = 0.f, D = 0.f, tn = 0.f, tf = __builtin_inff();
+    float su = 0.f, sv = 0.f, eu = 0.f, ev = 0.f, D = 0.f, tn = 0.f, tf = __builtin_inff(), gSlope = 0.f, gInvDu = 0.f;
     int slab = 0, slabLast = 0, slabStep = 1;  // the ray's next slab, its last one, the walk's direction (front to back)
     bool pending = false;
     {
@@ -945,6 +951,7 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
             ev = (__builtin_fmaf(tf, dv, ov) - G.g0v) * G.invH;
             // points are good to ~1e-5 scene units x 1/h here (|t d| <= the scene's size); the slack of the walk covers it
             D = G.rmaxOverH + reach * G.invH + kGridSlack;
+            grid_segment_slope(su, sv, eu, ev, gSlope, gInvDu);
             const float fa = __builtin_floorf(__builtin_fminf(su, eu) - D - kGridSlack), fb = __builtin_floorf(__builtin_fmaxf(su, eu) + D + kGridSlack);
             const int iuA = fa < 0.f ? 0 : (int)fa, iuB = fb > (float)(G.nu - 1u) ? (int)G.nu - 1 : (int)fb;
             if (iuA <= iuB && fb >= 0.f) {
@@ -1013,11 +1020,9 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
                 const uint32_t tb = reinterpret_cast<const uint32_t*>(best + lane)[1];
                 if (tb < 0x7f800000u) {
                     // where the walk enters the neighbourhood of slab `slab` (grid_slab_rows' sEnter), against the far limit
-                    const float du = eu - su;
-                    const float uNear = du > 0.f ? __builtin_fmaxf(__builtin_fminf(su, eu), (float)slab - D - kGridSlack)
-                                                 : __builtin_fminf(__builtin_fmaxf(su, eu), (float)(slab + 1) + D + kGridSlack);
-                    const bool steep = __builtin_fabsf(du) < 1e-4f * __builtin_fmaxf(__builtin_fabsf(ev - sv), 1.f);
-                    const float sEnter = steep ? 0.f : __builtin_fminf(__builtin_fmaxf((__builtin_fabsf(uNear - su) - kGridSlack) / __builtin_fabsf(du), 0.f), 1.f);
+                    const float uNear = eu > su ? __builtin_fmaxf(__builtin_fminf(su, eu), (float)slab - D - kGridSlack)
+                                                : __builtin_fminf(__builtin_fmaxf(su, eu), (float)(slab + 1) + D + kGridSlack);
+                    const float sEnter = __builtin_fminf(__builtin_fmaxf((__builtin_fabsf(uNear - su) - kGridSlack) * gInvDu * (1.f - 0x1p-20f), 0.f), 1.f);
                     if (__builtin_fmaf(sEnter, tf - tn, tn) > __uint_as_float(tb) * (1.f + 0x1p-10f)) cnt = 0;  // every later slab starts farther still
                 }
                 if (cnt == 0u) pending = false;
@@ -1045,9 +1050,10 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
             const float fa = lane_fetch(r, a), fdO = lane_fetch(r, dO), fcr = lane_fetch(r, crLeaf), fbt = lane_fetch(r, bt);
             const float fun = lane_fetch(r, boxUn), fuf = lane_fetch(r, boxUf);
             const float fsu = lane_fetch(r, su), fsv = lane_fetch(r, sv), feu = lane_fetch(r, eu), fev = lane_fetch(r, ev), fD = lane_fetch(r, D);
+            const float fsl = lane_fetch(r, gSlope), fiv = lane_fetch(r, gInvDu);
             int r0, r1;
             float sEnter;
-            grid_slab_rows(fsu, fsv, feu, fev, fD, iu, nv, r0, r1, sEnter);
+            grid_slab_rows(fsu, fsv, feu, fev, fD, fsl, fiv, iu, nv, r0, r1, sEnter);
             uint32_t eb = 0u, ee = 0u;
             if (has && r0 <= r1) {
                 // the slab's cells r0..r1 are consecutive, and so are their spheres in the scan table

@@ -224,7 +224,7 @@ uint32_t rt_rowset_global_row(rt_rowset rs, uint32_t local_row);
 
 /* --------------------------------------------------- unit-level entry points
  * Batched, device-evaluated pieces of the path, so that each reference function
- * has a GPU-vs-oracle known-answer test (tests/test_gpu_units.py).  All buffers
+ * has a GPU-vs-oracle known-answer test (tests/test_gpu_parity.py).  All buffers
  * are host memory; n elements. */
 
 /* Random::HaltonSample — quasi-random.cpp:3-16 */
