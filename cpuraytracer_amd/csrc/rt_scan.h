@@ -921,7 +921,6 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
     wave_lds_handoff();
     uint32_t nWork = 0, nExact = 0;
     // the ray clipped to the padded box of the grid's spheres (the derivation is the hierarchy scan's, above)
-    float boxUn = -__builtin_inff(), boxUf = __builtin_inff();
     float su = 0.f, sv = 0.f, eu = 0.f, ev = 0.f, D = 0.f, tn = 0.f, tf = __builtin_inff(), gSlope = 0.f, gInvDu = 0.f;
     int slab = 0, slabLast = 0, slabStep = 1;  // the ray's next slab, its last one, the walk's direction (front to back)
     bool pending = false;
@@ -940,8 +939,6 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
         tn *= 1.f - 0x1p-10f;
         tf *= 1.f + 0x1p-10f;
         const bool hitsBox = live && !(tn > tf || !(tf > 0.f)) && tf < 3.0e38f;
-        if (tn > 0.f) boxUn = a * tn;
-        boxUf = a * tf;
         if (hitsBox) {
             const float ou = G.axU == 0u ? o.x : (G.axU == 1u ? o.y : o.z), ov = G.axV == 0u ? o.x : (G.axV == 1u ? o.y : o.z);
             const float du = G.axU == 0u ? d.x : (G.axU == 1u ? d.y : d.z), dv = G.axV == 0u ? d.x : (G.axV == 1u ? d.y : d.z);
@@ -1048,9 +1045,10 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
             const V3 fg = v3(lane_fetch(r, gx), lane_fetch(r, gy), lane_fetch(r, gz));
             const V3 fd = v3(lane_fetch(r, d.x), lane_fetch(r, d.y), lane_fetch(r, d.z));
             const float fa = lane_fetch(r, a), fdO = lane_fetch(r, dO), fcr = lane_fetch(r, crLeaf), fbt = lane_fetch(r, bt);
-            const float fun = lane_fetch(r, boxUn), fuf = lane_fetch(r, boxUf);
             const float fsu = lane_fetch(r, su), fsv = lane_fetch(r, sv), feu = lane_fetch(r, eu), fev = lane_fetch(r, ev), fD = lane_fetch(r, D);
             const float fsl = lane_fetch(r, gSlope), fiv = lane_fetch(r, gInvDu);
+            const float ftn = lane_fetch(r, tn), ftf = lane_fetch(r, tf);
+            const float fun = ftn > 0.f ? fa * ftn : -__builtin_inff(), fuf = fa * ftf;  // the owner's boxUn, boxUf: the same products
             int r0, r1;
             float sEnter;
             grid_slab_rows(fsu, fsv, feu, fev, fD, fsl, fiv, iu, nv, r0, r1, sEnter);
@@ -1061,8 +1059,7 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
                 ee = (uint32_t)cellStart[iu * nv + r1 + 1];
                 // (a slab the ray enters beyond its closest hit so far has nothing to add)
                 const uint32_t tb0 = reinterpret_cast<const uint32_t*>(best + r)[1];
-                const float ftn = fun > 0.f ? fun / fa : 0.f;  // tn and tf back from the box limits a * t
-                if (tb0 < 0x7f800000u && __builtin_fmaf(sEnter, fuf / fa - ftn, ftn) > __uint_as_float(tb0) * (1.f + 0x1p-9f)) ee = eb;
+                if (tb0 < 0x7f800000u && __builtin_fmaf(sEnter, ftf - ftn, ftn) > __uint_as_float(tb0) * (1.f + 0x1p-10f)) ee = eb;
             }
             // four spheres per step; every lane runs as many steps as the longest run of the round needs
             while (__ballot(eb < ee) != 0ull) {
