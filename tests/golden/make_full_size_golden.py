@@ -35,6 +35,10 @@ CONFIGS = {
     "c3": ("cover", 1200, 800, 1024, 50, -1.0, 1, 1),
     "c4": ("cover", 1920, 1080, 512, 50, 2.0, 1, 1),
     "c5": ("grid10k", 4096, 4096, 64, 50, -1.0, 1, 1),
+    # beyond BASELINE.json: the headline job on other scenes / streams (scene seed, render seed), against seed-specific luck
+    "c2_scene2": ("cover", 1200, 800, 128, 50, -1.0, 2, 1),
+    "c2_scene3_seed7": ("cover", 1200, 800, 128, 50, -1.0, 3, 7),
+    "c5_small_scene2": ("grid10k", 1024, 1024, 32, 50, -1.0, 2, 5),
 }
 
 

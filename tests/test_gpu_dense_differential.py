@@ -53,10 +53,11 @@ def _assert_matches_digest(name, st, hdr, ldr):
     assert hashlib.sha256(np.ascontiguousarray(ldr).tobytes()).hexdigest() == rec["ldr_sha256"], "%s: LDR bytes differ" % name
 
 
-@pytest.mark.parametrize("name", ["c2", "c4", "c5", "c3"])
+@pytest.mark.parametrize("name", ["c2", "c4", "c5", "c3", "c2_scene2", "c2_scene3_seed7", "c5_small_scene2"])
 def test_full_size_config_equals_the_oracles_render_of_every_path(hip, scenes_mod, name):
-    """BASELINE.json configs[1..4] at full size on one device: totals, HDR bits and LDR bytes of the whole job equal the
-    oracle's (list-scan semantics, PaddedListTree) — every one of the job's paths is compared, through the committed digests."""
+    """BASELINE.json configs[1..4] at full size on one device (and the headline job on two other random scenes / streams, and a
+    smaller job on another 10,004-sphere scene): totals, HDR bits and LDR bytes of the whole job equal the oracle's (list-scan
+    semantics, PaddedListTree) — every one of the job's paths is compared, through the committed digests."""
     rec = DIGESTS[name]
     hip.upload(_scene_for(scenes_mod, rec))
     st = hip.render(rec["W"], rec["H"], 1, 1 + rec["spp"], rec["depth"], rec["render_seed"])
