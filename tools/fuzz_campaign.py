@@ -24,6 +24,8 @@ for seed in range(first, first + count):
     so = orc.render(W, H, 1, 1 + spp, depth, 9 + seed, accel=oracle.ACCEL_PADDED_LIST, threads=16); ho, _ = orc.download()
     npx = int((hg.view(np.uint32) != ho.view(np.uint32)).any(axis=-1).sum())
     ok = npx == 0 and sg.traversals == so.traversals and sg.segments == so.segments
+    if (seed - first) % 100 == 99:
+        print("  ... %d scenes, %d mismatching, %.0f s" % (seed - first + 1, bad, time.time() - t0), flush=True)
     if not ok:
         bad += 1
         print("MISMATCH seed %d n %d scale %g off %s %dx%d spp %d depth %d: %d pixels, trav %d vs %d, seg %d vs %d" % (
