@@ -66,6 +66,24 @@ def test_full_size_config_equals_the_oracles_render_of_every_path(hip, scenes_mo
     _assert_matches_digest(name, st, hdr, ldr)
 
 
+def test_c3_job_passes_through_the_c2_image_after_128_samples(hip, scenes_mod):
+    """BASELINE config 3 is config 2's accumulation carried on to spp 1024: rendered progressively, the strip after samples
+    1..128 is C2's image (its digest) and after 129..1024 it is C3's."""
+    rec2, rec3 = DIGESTS["c2"], DIGESTS["c3"]
+    hip.upload(_scene_for(scenes_mod, rec3))
+    st = hip.render(rec3["W"], rec3["H"], 1, 129, rec3["depth"], rec3["render_seed"])
+    hip.resolve()
+    hdr, ldr = hip.download()
+    _assert_matches_digest("c2", st, hdr, ldr)
+    st2 = hip.render(rec3["W"], rec3["H"], 129, 1025, rec3["depth"], rec3["render_seed"])
+    hip.resolve()
+    hdr, ldr = hip.download()
+    assert st.traversals + st2.traversals == rec3["traversals"] and st.segments + st2.segments == rec3["segments"]
+    assert hashlib.sha256(np.ascontiguousarray(hdr, dtype="<f4").tobytes()).hexdigest() == rec3["hdr_sha256"]
+    assert hashlib.sha256(np.ascontiguousarray(ldr).tobytes()).hexdigest() == rec3["ldr_sha256"]
+    assert rec2["samples"] * 8 == rec3["samples"]
+
+
 def _live_oracle_frame(oracle, sc, W, H, spp, depth, seed):
     orc = oracle.Oracle()
     orc.upload(sc)
