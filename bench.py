@@ -21,7 +21,7 @@ Rank 0 prints ONE JSON line.
 
 roofline: the trace kernel is bound by VALU ISSUE (the matrix cores share the SIMD's
 issue port).  `achieved` = executed VALU lane-operations per launch (SQ_THREAD_CYCLES_VALU = SQ_INSTS_VALU x 64 x
-lane utilisation, from the committed rocprofv3 --pmc passes of this same command, profiles/r03_pmc_summary*.json)
+lane utilisation, from the committed rocprofv3 --pmc passes of this same command, profiles/r04_pmc_summary*.json)
 divided by the launch duration measured LIVE in this run with HIP events on the kernel's stream; `peak` = 78.6 T
 lane-op/s (256 CU x 4 SIMD x 64 lanes / 2 cycles x 2.4 GHz).  The instruction counts are a property of (kernel
 binary, workload): the PMC summary records the hash of the kernel sources it was taken from, and the roofline object
@@ -43,13 +43,13 @@ SCENE_SEED, RENDER_SEED = 1, 1
 CONFIGS = {
     # name: scene, W, H, spp per GPU, aperture (-1 = the scene's own), metric text, PMC summary
     "c2": dict(scene="cover", W=1200, H=800, spp=128, aperture=-1.0,
-               metric="Msamples/sec (WxHxspp/s), 1200x800 cover scene spp=128 d=50", pmc="r03_pmc_summary.json"),
+               metric="Msamples/sec (WxHxspp/s), 1200x800 cover scene spp=128 d=50", pmc="r04_pmc_summary.json"),
     "c3": dict(scene="cover", W=1200, H=800, spp=1024, aperture=-1.0,  # BASELINE config 3's whole job on ONE GPU: one 11.8 GB pass
-               metric="Msamples/sec (WxHxspp/s), 1200x800 cover scene spp=1024 d=50", pmc="r03_pmc_summary_c3.json"),
+               metric="Msamples/sec (WxHxspp/s), 1200x800 cover scene spp=1024 d=50", pmc="r04_pmc_summary_c3.json"),
     "c4": dict(scene="cover", W=1920, H=1080, spp=512, aperture=2.0,
-               metric="Msamples/sec (WxHxspp/s), 1920x1080 cover scene aperture=2.0 spp=512 d=50", pmc="r03_pmc_summary_c4.json"),
+               metric="Msamples/sec (WxHxspp/s), 1920x1080 cover scene aperture=2.0 spp=512 d=50", pmc="r04_pmc_summary_c4.json"),
     "c5": dict(scene="grid10k", W=4096, H=4096, spp=64, aperture=-1.0,
-               metric="Msamples/sec (WxHxspp/s), 4096x4096 grid10k scene (10,004 spheres) spp=64 d=50", pmc="r03_pmc_summary_c5.json"),
+               metric="Msamples/sec (WxHxspp/s), 4096x4096 grid10k scene (10,004 spheres) spp=64 d=50", pmc="r04_pmc_summary_c5.json"),
 }
 PEAK_VALU_TLANEOPS = 78.6   # 256 CU x 4 SIMD x 64 lanes / 2 cycles per wave-instruction x 2.4 GHz (MI355X_MICROARCH.md: SIMD-32, 2 cycles)
 PEAK_HBM_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
@@ -77,8 +77,13 @@ def cpu_baseline(cfg, target_seconds=15.0):
     # a one-GPU box's CPU share is 16 cores; RT_CPU_BASELINE_THREADS overrides
     cores = int(os.environ.get("RT_CPU_BASELINE_THREADS", min(avail, 16)))
     W, H = cfg["W"], cfg["H"]
-    if W * H > 2000000:  # C5: a 1024x1024 crop-equivalent frame of the same scene and camera keeps the sample bounded
+    reduced = ""
+    if cfg["scene"] == "grid10k" and W * H > 4000000:
+        # C5 only: one full 4096x4096 frame is ~1 minute of oracle time, so the sample is the SAME camera and aspect (1:1) at
+        # 1024x1024 -- a 4x coarser pixel grid over the same picture, not a crop; every other config renders its own frame size
+        # and is bounded by spp alone
         W, H = 1024, 1024
+        reduced = " (same camera at 1/4 linear resolution of %dx%d)" % (cfg["W"], cfg["H"])
     sc = O.build_scene(cfg["scene"], SCENE_SEED, cfg["W"] / float(cfg["H"]), cfg["aperture"])
     orc = O.Oracle()
     orc.upload(sc)
@@ -93,8 +98,8 @@ def cpu_baseline(cfg, target_seconds=15.0):
         orc.resolve()
         t1 = time.perf_counter() - t0
     return {"value": st.samples / t1 / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%s scene %dx%d depth %d at spp=%d (of %d), BvhNode traversal, %d std::thread workers, %.1f s"
-                      % (cfg["scene"], W, H, DEPTH, spp, cfg["spp"], cores, t1)}
+            "sample": "%s scene %dx%d%s depth %d at spp=%d (of %d), BvhNode traversal, %d std::thread workers, %.1f s"
+                      % (cfg["scene"], W, H, reduced, DEPTH, spp, cfg["spp"], cores, t1)}
 
 
 def roofline_object(cfg, kernel_name, avg_ms, avg_trav, n_spheres, src_hash, n_gpus=1):
@@ -142,6 +147,10 @@ def roofline_object(cfg, kernel_name, avg_ms, avg_trav, n_spheres, src_hash, n_g
                 "frac x (1/lane_utilisation) = fraction of VALU issue slots used at 2.4 GHz",
     })
     cull = FLOPS_PER_SPHERE_TEST * avg_trav * n_spheres / lane_ops
+    # SURVEY.md 8(d)'s own unit beside the executed-work fraction: 18 flop x N x T per launch / time / peak.  The kernel does not
+    # run exhaustive scans (it culls, as the reference's BVH does), so this exceeds 1 by about the cull factor x frac.
+    rl["frac_algorithmic"] = FLOPS_PER_SPHERE_TEST * avg_trav * n_spheres / (avg_ms * 1e-3) / 1e12 / PEAK_VALU_TLANEOPS
+    rl["frac_algorithmic_note"] = "18*N*T / t / peak (SURVEY.md 8d); > 1 => culled: the filters skip that share of the exhaustive scan"
     return rl, {"value": cull, "algorithmic": "18 flop x %d spheres x %.0f list scans per launch (SURVEY.md 8d) / executed VALU lane-operations"
                                               % (n_spheres, avg_trav)}
 

@@ -44,6 +44,13 @@ uint32_t EnvU32(const char* name, uint32_t dflt) {
     return (uint32_t)std::strtoul(v, nullptr, 10);
 }
 
+// Largest top level the matrix-core filter takes (RT_TREE_TOP, default 128 = four tiles of 32): one reader for rt_create and for
+// the GPU-less layout queries (rt_unit_layout, rt_unit_layout_info), so that they describe the layout an upload would build.
+uint32_t TreeTopFromEnv() {
+    const uint32_t t = EnvU32("RT_TREE_TOP", 128);
+    return (t < 4 || t > 128) ? 128u : t;
+}
+
 template <typename T>
 struct DevBuf {
     T* ptr = nullptr;
@@ -836,27 +843,31 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     // (RT_STASH=0: the path-cache variants; RT_STASH_CAP: fewer records).  depth shares its register with the scan entry.
     bool useStash = false, matsL2 = false;
     {
-        size_t room = 160 * 1024 / ctx->blocksPerCu > ldsBytes ? (160 * 1024 / ctx->blocksPerCu - ldsBytes) / wavesPerBlock / 16 * 16 : 0;
-        uint32_t cap = (uint32_t)(room / (rtd::kStashDwords * 4));
+        const size_t budget = 160 * 1024 / ctx->blocksPerCu;
         const uint32_t capEnv = EnvU32("RT_STASH_CAP", 63u);
+        auto capFor = [&](size_t imageBytes) -> uint32_t {  // records per wave that fit behind an image of this size
+            if (budget <= imageBytes) return 0u;
+            const size_t room = (budget - imageBytes) / wavesPerBlock / 16 * 16;
+            uint32_t c = (uint32_t)(room / (rtd::kStashDwords * 4));
+            c = c > 63u ? 63u : c;
+            return c > capEnv ? capEnv : c;
+        };
+        const bool stashKernel = ctx->useStash && carryMode == 0 && (flat || tree || grid) && ctx->blockThreads == 1024 && tp.max_depth < 65536u;
+        uint32_t cap = capFor(ldsBytes);
         // Flat variant: when the material table's 48 bytes per sphere would buy at least eight more records per wave, the
-        // materials are read through L2 instead (kMatsL2; measured on the cover scene: 44 -> 63 records, +1 %; RT_MATS_L2=0: never)
-        if (flat && tp.mats_in_lds && (sgBytes != 0 || !tp.sg_enabled) && cap < 63u && cap < capEnv && EnvU32("RT_MATS_L2", 1u) != 0u && ctx->useStash &&
-            carryMode == 0 && ctx->blockThreads == 1024 && tp.max_depth < 65536u) {  // (exactly when the stash variant will be launched)
+        // materials are read through L2 instead (kMatsL2; measured on the cover scene: 44 -> 63 records, +1 %; RT_MATS_L2=0: never).
+        // Decided on the candidate image WITHOUT touching ldsBytes: the smaller image is committed only together with the stash
+        // variant that is built for it (the other flat kernels stage the material table and need its room).
+        if (stashKernel && flat && tp.mats_in_lds && (sgBytes != 0 || !tp.sg_enabled) && EnvU32("RT_MATS_L2", 1u) != 0u) {
             const size_t matBytes = (size_t)tp.n_padded * 48;
-            const size_t room2 = (160 * 1024 / ctx->blocksPerCu - (ldsBytes - matBytes)) / wavesPerBlock / 16 * 16;
-            uint32_t cap2 = (uint32_t)(room2 / (rtd::kStashDwords * 4));
-            cap2 = cap2 > 63u ? 63u : cap2;
-            if (cap2 >= cap + 8u) {
+            const uint32_t cap2 = matBytes <= ldsBytes ? capFor(ldsBytes - matBytes) : 0u;
+            if (cap2 >= cap + 8u && cap2 >= 16u) {
                 matsL2 = true;
                 ldsBytes -= matBytes;
-                room = room2;
                 cap = cap2;
             }
         }
-        cap = cap > 63u ? 63u : cap;
-        cap = cap > capEnv ? capEnv : cap;
-        if (ctx->useStash && carryMode == 0 && (flat || tree || grid) && ctx->blockThreads == 1024 && tp.max_depth < 65536u && cap >= 16u) {
+        if (stashKernel && cap >= 16u) {
             useStash = true;
             tp.stash_cap = cap;
             const uint32_t procEnv = EnvU32("RT_STASH_PROCESS", 63u);  // experiments: process hits from this many + 1 lanes on
@@ -865,6 +876,7 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
             tp.ray_cache_stride16 = (cap * rtd::kStashDwords * 4 + 15) / 16;
             ldsBytes += (size_t)wavesPerBlock * tp.ray_cache_stride16 * 16;
         }
+        if (matsL2 && !useStash) return Fail(RT_ERR_HIP, "internal: materials through L2 without the stash variant");
     }
     if (!useStash && ctx->useRayCache && ldsBytes + (size_t)wavesPerBlock * rtd::kRayCacheBytes <= 160 * 1024 / ctx->blocksPerCu) {
         tp.ray_cache_off16 = (uint32_t)(ldsBytes / 16);
@@ -1190,8 +1202,7 @@ int rt_create(int device_ordinal, rt_ctx** out) {
         ctx->useStash = EnvU32("RT_STASH", 1) != 0;
         ctx->treeInLds = EnvU32("RT_TREE_LDS", 1) != 0;
         ctx->useTileOrder = EnvU32("RT_TILE_ORDER", 1) != 0;
-        ctx->treeTop = EnvU32("RT_TREE_TOP", 128);
-        if (ctx->treeTop < 4 || ctx->treeTop > 128) ctx->treeTop = 128;
+        ctx->treeTop = TreeTopFromEnv();
     }
     // launch geometry (sweeps: profiles/r01_sweep_*.jsonl): the matrix-core scan wants 16 waves per CU in ONE
     // 1024-thread workgroup (one LDS image, 128 VGPRs); the pure-VALU scan runs 4 x 256 threads
@@ -1470,6 +1481,12 @@ static int BatchFlush(rt_ctx* ctx) {
     return RenderNow(ctx, ctx->pendW, ctx->pendH, ctx->pendRs, ctx->pendS0, ctx->pendS1, ctx->pendDepth, ctx->pendSeed, nullptr);
 }
 
+// The readers (rt_resolve, rt_download, rt_copy_to_device) hand out the COMMITTED strip while a batch that continues it is
+// pending.  A pending batch that does not continue it -- nothing is committed yet, or its first call had s0 == 1 and so starts a
+// new accumulation, possibly of another size: the caller's picture is the new one, and ctx->W / ctx->rows still describe the old
+// strip -- is rendered first.
+static bool PendingMustRender(const rt_ctx* ctx) { return ctx->pendOn && (ctx->accumulated == 0 || ctx->pendS0 == 1u); }
+
 int rt_set_frame_batch(rt_ctx* ctx, uint32_t frames) {
     if (!ctx || frames == 0 || frames > 4096) return Fail(RT_ERR_INVALID_ARG, "rt_set_frame_batch: frames must be 1..4096");
     RT_HIP(hipSetDevice(ctx->device));
@@ -1669,7 +1686,7 @@ static int RenderNow(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t
 
 int rt_resolve(rt_ctx* ctx, uint32_t n_samples) {
     if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_resolve: null ctx");
-    if (ctx->accumulated == 0 && ctx->pendOn) {  // nothing committed yet: the pending frames are what there is to show
+    if (PendingMustRender(ctx)) {  // nothing committed yet, or the pending frames START a new accumulation: they are what there is to show
         const int rcb = BatchFlush(ctx);
         if (rcb != RT_OK) return rcb;
     }
@@ -1695,7 +1712,7 @@ double rt_last_resolve_ms(rt_ctx* ctx) { return ctx ? ctx->lastResolveMs : 0.0; 
 
 int rt_download(rt_ctx* ctx, float* hdr_rgb, uint8_t* ldr_rgb) {
     if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_download: null ctx");
-    if (ctx->accumulated == 0 && ctx->pendOn) {
+    if (PendingMustRender(ctx)) {
         const int rcb = BatchFlush(ctx);
         if (rcb != RT_OK) return rcb;
     }
@@ -1710,7 +1727,7 @@ int rt_download(rt_ctx* ctx, float* hdr_rgb, uint8_t* ldr_rgb) {
 
 int rt_copy_to_device(rt_ctx* ctx, void* dev_hdr_rgb, void* dev_ldr_rgb) {
     if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_copy_to_device: null ctx");
-    if (ctx->accumulated == 0 && ctx->pendOn) {
+    if (PendingMustRender(ctx)) {
         const int rcb = BatchFlush(ctx);
         if (rcb != RT_OK) return rcb;
     }
@@ -1917,7 +1934,7 @@ int rt_unit_tonemap(rt_ctx* ctx, const float* hdr_rgb, uint32_t n, uint32_t n_sa
 int rt_unit_layout(const rt_sphere* spheres, uint32_t n, uint32_t cap_groups, uint32_t* n_groups, uint32_t* orig, float* bounds) {
     if (!spheres || n == 0 || !n_groups) return Fail(RT_ERR_INVALID_ARG, "rt_unit_layout: invalid argument");
     SceneLayout L;
-    BuildLayout(spheres, n, 128, L);
+    BuildLayout(spheres, n, TreeTopFromEnv(), L);
     *n_groups = L.nGroups;
     if (cap_groups == 0) return RT_OK;
     if (cap_groups < L.nGroups || !orig || !bounds) return Fail(RT_ERR_INVALID_ARG, "rt_unit_layout: capacity too small");
@@ -1929,7 +1946,7 @@ int rt_unit_layout(const rt_sphere* spheres, uint32_t n, uint32_t cap_groups, ui
 int rt_unit_layout_info(const rt_sphere* spheres, uint32_t n, uint32_t out[5]) {
     if (!spheres || n == 0 || !out) return Fail(RT_ERR_INVALID_ARG, "rt_unit_layout_info: invalid argument");
     SceneLayout L;
-    BuildLayout(spheres, n, 128, L);
+    BuildLayout(spheres, n, TreeTopFromEnv(), L);
     out[0] = L.gridOn ? 1u : (L.nLevels > 1 ? 2u : 0u);
     out[1] = L.gridOn ? L.gridNu : 0u;
     out[2] = L.gridOn ? L.gridNv : 0u;

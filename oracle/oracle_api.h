@@ -38,7 +38,7 @@ void orc_set_sampler(uint32_t flags);
 /* CPU-only diagnostic: GetHitColor in the reference's nesting L = (E+S) + a*(...) (spheres-app.cpp:249-251) instead of
  * the forward radiance += throughput*(E+S) form that the path's contract (and the HIP kernel) uses */
 void orc_use_nested_radiance(int on);
-void orc_use_reference_bvh_tie_rule(int on);  /* CPU diagnostic: exact ties go to the BVH's right child (the reference's rule) */
+void orc_use_reference_bvh_tie_rule(int on);  /* default 1: ORC_ACCEL_BVH gives exact ties to the right child (the reference's rule); 0 (diagnostic): to the lower list index, like the list scan */
 int orc_clear(orc_ctx* ctx);
 int orc_resolve(orc_ctx* ctx, uint32_t n_samples);
 int orc_download(orc_ctx* ctx, float* hdr_rgb, uint8_t* ldr_rgb);

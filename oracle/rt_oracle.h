@@ -94,7 +94,8 @@ uint32_t ScriptDrawsUsed();
 // CPU-only diagnostic: evaluate GetHitColor in the reference's own nesting (spheres-app.cpp:249-251) instead of the
 // forward throughput form that is the path's contract (see GetHitColorNested in rt_oracle.cpp).
 void UseNestedRadiance(bool on);
-// CPU-only diagnostic: BvhNode::Intersect gives exact ties to the right child, as the reference does (see rt_oracle.cpp).
+// BvhNode::Intersect gives exact ties to the right child, as the reference does (default, true); false (CPU diagnostic): to the
+// lower list index, the list scan's rule (see rt_oracle.cpp).
 void UseReferenceBvhTieRule(bool on);
 bool NestedRadiance();
 

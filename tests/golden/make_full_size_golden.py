@@ -12,6 +12,11 @@ mismatch names its rows).  tests/test_gpu_parity.py asserts the HIP path against
 9.8e8 (C3), 1.06e9 (C4) and 1.07e9 (C5) paths at the cost of one hash per image on the GPU box.
 
 Usage: python tests/golden/make_full_size_golden.py [c2 c3 c4 c5] [--threads N]
+       python tests/golden/make_full_size_golden.py --accel list c2 c2_scene2 [--threads N]
+--accel list (round 4): render the job again with the PLAIN LIST (oracle ACCEL_LIST: Sphere::Intersect for every sphere of
+every scan, 2.3e11 sphere tests per C2 job) and compare with the recorded digest made through PaddedListTree; on equality
+the record gets "list_verified": true (+ the seconds it took); on a mismatch the script says so and exits 1 without
+touching the record -- the digest, not the GPU, is then what has to be fixed first.
 """
 import hashlib
 import json
@@ -59,14 +64,43 @@ def main():
     if "--threads" in sys.argv:
         threads = int(sys.argv[sys.argv.index("--threads") + 1])
         args = [a for a in args if a != str(threads)]
+    verify_list = False
+    if "--accel" in sys.argv:
+        mode = sys.argv[sys.argv.index("--accel") + 1]
+        if mode not in ("list", "padded"):
+            raise SystemExit("--accel takes 'list' or 'padded'")
+        verify_list = mode == "list"
+        args = [a for a in args if a != mode]
     todo = args or list(CONFIGS)
     out = json.load(open(OUT)) if os.path.exists(OUT) else {}
     orc = O.Oracle()
+    bad = 0
     for name in todo:
         scene, W, H, spp, depth, ap, sseed, rseed = CONFIGS[name]
         sc = O.build_scene(scene, sseed, W / H, ap)
         orc.upload(sc)
         t = time.time()
+        if verify_list:
+            st = orc.render(W, H, 1, 1 + spp, depth, rseed, accel=O.ACCEL_LIST, threads=threads)
+            orc.resolve()
+            hdr, ldr = orc.download()
+            d = digests(hdr, ldr)
+            rec = out[name]
+            same = (d["hdr_sha256"] == rec["hdr_sha256"] and d["ldr_sha256"] == rec["ldr_sha256"] and
+                    int(st.traversals) == rec["traversals"] and int(st.segments) == rec["segments"])
+            print(name, "plain list:", d["hdr_sha256"][:16], "recorded:", rec["hdr_sha256"][:16], "EQUAL" if same else "DIFFERENT",
+                  round(time.time() - t, 1), "s", flush=True)
+            if not same:
+                bad += 1
+                rows = [j for j, (a, b) in enumerate(zip(d["hdr_row_crc32"], rec["hdr_row_crc32"])) if a != b]
+                print("  rows that differ:", rows[:40], flush=True)
+                continue
+            rec["list_verified"] = True
+            rec["list_oracle"] = "oracle/liboracle.so orc_render, ACCEL_LIST (plain HitableList scan), %d threads, %.0f s" % (threads, time.time() - t)
+            with open(OUT, "w") as f:
+                json.dump(out, f, indent=0, sort_keys=True)
+                f.write("\n")
+            continue
         st = orc.render(W, H, 1, 1 + spp, depth, rseed, accel=O.ACCEL_PADDED_LIST, threads=threads)
         orc.resolve()
         hdr, ldr = orc.download()
@@ -80,6 +114,8 @@ def main():
             json.dump(out, f, indent=0, sort_keys=True)
             f.write("\n")
         print(name, rec["samples"], rec["traversals"], rec["segments"], rec["hdr_sha256"][:16], rec["oracle_seconds"], "s", flush=True)
+    if bad:
+        raise SystemExit(1)
 
 
 if __name__ == "__main__":

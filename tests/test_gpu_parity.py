@@ -773,6 +773,54 @@ def test_batched_progressive_frames_equal_the_one_shot_render(hip, scenes_mod, s
         one.close()
 
 
+def test_readers_render_a_pending_batch_that_starts_a_new_picture(hip, scenes_mod):
+    """with an accumulation committed, a deferred call with s0 == 1 starts a NEW one -- here of a smaller image.
+    rt_resolve / rt_download / rt_copy_to_device must render it first: they used to hand out the OLD strip with the old size into a
+    buffer the caller sized for the new picture (heap overflow when the new strip is smaller, a stale frame otherwise)."""
+    from cpuraytracer_amd import HipRenderer
+    # the HIP runtime librt_hip.so itself is linked against (it is loaded already): the caller-owned device memory of this test
+    maps = open("/proc/self/maps").read()
+    hiprt = C.CDLL(next(l.split()[-1] for l in maps.splitlines() if "libamdhip64.so" in l))
+    sc = scenes_mod.build_scene("cover", 1, 160, 100)
+    one = HipRenderer(0)
+    one.upload(sc)
+    hip.upload(sc)
+    try:
+        hip.render(160, 100, 1, 5, 50, 1)  # committed: 160x100, four samples
+        hip.set_frame_batch(8)
+        for (W, H, seed) in ((96, 40, 3), (200, 120, 4)):  # smaller, then larger than the committed strip
+            hip.render(W, H, 1, 2, 50, seed, stats=False)  # deferred; starts a new accumulation
+            hip.render(W, H, 2, 4, 50, seed, stats=False)  # continues the pending batch
+            hip.resolve()
+            h_new, l_new = hip.download()
+            assert h_new.shape == (H, W, 3) and hip.committed_samples() == 3
+            one.render(W, H, 1, 4, 50, seed)
+            one.resolve()
+            h_ref, l_ref = one.download()
+            assert_same(h_new, h_ref, "download of a pending batch that starts a new %dx%d picture" % (W, H))
+            assert_same(l_new, l_ref, "LDR of that picture")
+            # device-to-device reader: the same strip, and not a byte beyond it
+            n = H * W * 3 + 1024
+            fill = np.full(n, np.float32(-7.0), dtype=np.float32)
+            dev = C.c_void_p()
+            assert hiprt.hipMalloc(C.byref(dev), C.c_size_t(4 * n)) == 0
+            try:
+                assert hiprt.hipMemcpy(dev, C.c_void_p(fill.ctypes.data), C.c_size_t(4 * n), 1) == 0  # host to device
+                hip.render(W, H, 1, 2, 50, seed + 10, stats=False)  # again a pending start on top of a committed accumulation
+                hip.copy_to_device(dev.value, None)
+                hip.synchronize()
+                got = np.zeros(n, dtype=np.float32)
+                assert hiprt.hipMemcpy(C.c_void_p(got.ctypes.data), dev, C.c_size_t(4 * n), 2) == 0  # device to host
+            finally:
+                hiprt.hipFree(dev)
+            one.render(W, H, 1, 2, 50, seed + 10)
+            assert_same(got[:H * W * 3].reshape(H, W, 3), one.download(ldr=False)[0], "copy_to_device of a pending new picture")
+            assert (got[H * W * 3:] == -7.0).all()
+    finally:
+        hip.set_frame_batch(1)
+        one.close()
+
+
 def test_pipelining_falls_back_where_the_variant_does_not_apply(hip, scenes_mod):
     """grid10k runs the hierarchy scan, which has no carrying variant: the same calls run unpipelined and stay exact."""
     sc = scenes_mod.build_scene("grid10k", 1, 96, 96)

@@ -388,22 +388,22 @@ def test_bvh_equals_list_on_random_rays_and_images(oracle):
 def test_exact_tie_goes_to_the_lower_list_index(oracle):
     """Found by the full-size differential of config C4 (sample (1226, 751, 386), third segment): a ray that meets spheres
     427 and 428 of the cover scene -- two overlapping small spheres -- at the SAME binary32 t.  The reference's BvhNode gives
-    an exact tie to the right child of a tree built on unseeded std::rand() axes (ray-tracing.cpp:121,184-191), so the
-    reference itself does not reproduce it; the path's contract is the list scan's rule, lower list index (SURVEY.md §8a
-    A6), and the oracle's BvhNode follows it.  The reference's rule stays selectable and picks the other sphere here."""
+    an exact tie to the right child (ray-tracing.cpp:184-191) -- the oracle's ACCEL_BVH restates that faithfully and picks 428
+    here; the path's contract is the list scan's rule, lower list index: 427.  With the tie rule switched to
+    the list's (diagnostic) BvhNode returns the list's record bit for bit."""
     sc = oracle.build_scene("cover", 1, 1.5)
     orc = oracle.Oracle()
     orc.upload(sc)
     ray = np.array([[5.776693344116211, -0.016715288162231445, 0.024381153285503387,
                      0.7938283681869507, 0.058303073048591614, -0.6053406596183777]], dtype=np.float32)
     hl = orc.closest_hit(ray, oracle.ACCEL_LIST)
-    hb = orc.closest_hit(ray, oracle.ACCEL_BVH)
-    assert int(hl[0, 1:2].view(np.int32)[0]) == 427 and np.array_equal(hl.view(np.uint32), hb.view(np.uint32))
-    oracle.lib().orc_use_reference_bvh_tie_rule(1)
+    hr = orc.closest_hit(ray, oracle.ACCEL_BVH)  # the reference's rule is the default
+    oracle.lib().orc_use_reference_bvh_tie_rule(0)
     try:
-        hr = orc.closest_hit(ray, oracle.ACCEL_BVH)
+        hb = orc.closest_hit(ray, oracle.ACCEL_BVH)
     finally:
-        oracle.lib().orc_use_reference_bvh_tie_rule(0)
+        oracle.lib().orc_use_reference_bvh_tie_rule(1)
+    assert int(hl[0, 1:2].view(np.int32)[0]) == 427 and np.array_equal(hl.view(np.uint32), hb.view(np.uint32))
     assert int(hr[0, 1:2].view(np.int32)[0]) == 428
     assert hr[0, 0:1].view(np.uint32)[0] == hl[0, 0:1].view(np.uint32)[0]  # the same t, bit for bit
     assert np.array_equal(hr[0, 2:5].view(np.uint32), hl[0, 2:5].view(np.uint32))  # hence the same position; the normals differ
@@ -464,11 +464,7 @@ def test_known_paths_where_the_reference_bvh_is_not_the_list(oracle):
         rl, tl = orc.trace(W, H, ijs, 50, 1, accel=oracle.ACCEL_LIST)
         rp, tp = orc.trace(W, H, ijs, 50, 1, accel=oracle.ACCEL_PADDED_LIST)
         assert np.array_equal(rl.view(np.uint32), rp.view(np.uint32)) and np.array_equal(tl, tp)
-        oracle.lib().orc_use_reference_bvh_tie_rule(1)
-        try:
-            rb, tb = orc.trace(W, H, ijs, 50, 1, accel=oracle.ACCEL_BVH)
-        finally:
-            oracle.lib().orc_use_reference_bvh_tie_rule(0)
+        rb, tb = orc.trace(W, H, ijs, 50, 1, accel=oracle.ACCEL_BVH)  # the faithful BvhNode: right-child ties, binary32 slabs
         assert (tb != tl).all()  # every one of them differs under the reference's accelerator
 
 
