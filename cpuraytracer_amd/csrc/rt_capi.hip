@@ -2011,4 +2011,29 @@ int rt_debug_stamps(rt_ctx* ctx, unsigned long long out[20]) {
 }
 #endif
 
+#ifdef RT_PHASES
+// Diagnostic build only (tools/phase_budget.py): read and clear the region counters (rt_params.h g_sites); out[2 * site] = wave
+// visits, out[2 * site + 1] = active lanes.  names: the sites' names, comma separated, in id order.
+int rt_debug_sites(rt_ctx* ctx, unsigned long long* out, uint32_t cap, const char** names) {
+    static const char* kNames =
+#define RT_SITE_NAME(n) #n ","
+        RT_SITE_LIST(RT_SITE_NAME)
+#undef RT_SITE_NAME
+        ;
+    if (names) *names = kNames;
+    if (!ctx || !out || cap < 2u * rtd::SITE_COUNT) return Fail(RT_ERR_INVALID_ARG, "rt_debug_sites: invalid argument");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    static unsigned long long raw[rtd::SITE_COUNT * 16];
+    RT_HIP(hipMemcpyFromSymbol(raw, HIP_SYMBOL(rtd::g_sites), sizeof(raw)));
+    for (uint32_t k = 0; k < rtd::SITE_COUNT; ++k) {
+        out[2 * k] = raw[16 * k];
+        out[2 * k + 1] = raw[16 * k + 1];
+    }
+    std::memset(raw, 0, sizeof(raw));
+    RT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_sites), raw, sizeof(raw)));
+    return RT_OK;
+}
+#endif
+
 }  // extern "C"

@@ -23,6 +23,7 @@
 // once-per-scene work (Camera::Camera, InitScene); nothing on the render path runs on the CPU.
 #define RT_DEV inline
 #endif
+#include "rt_sites.h"
 
 namespace rtd {
 
@@ -86,7 +87,10 @@ RT_DEV V3 div3(V3 v, float b) {
         return {div_rn(v.x, b, y), div_rn(v.y, b, y), div_rn(v.z, b, y)};
     }
 #endif
-    return {v.x / b, v.y / b, v.z / b};
+    {
+        RT_SITE(M_DIV_SLOW);
+        return {v.x / b, v.y / b, v.z / b};
+    }
 }
 
 // XMVector3Normalize (SSE2): zero length -> 0, infinite length -> QNaN, else true divide.

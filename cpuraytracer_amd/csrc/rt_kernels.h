@@ -52,6 +52,7 @@ constexpr uint32_t kStashDwords = 19;
 // list of the unit tests, or the tiled order below over the rows of this shard.  slot = index either way.
 RT_DEV void path_coordinates(const TraceParams& p, uint32_t q, uint32_t& i, uint32_t& j, uint32_t& s, uint32_t& slot) {
     if (p.path_list) {
+        RT_SITE(K_PATHLIST);
         i = p.path_list[3 * q];
         j = p.path_list[3 * q + 1];
         s = p.path_list[3 * q + 2];
@@ -74,6 +75,7 @@ RT_DEV void path_coordinates(const TraceParams& p, uint32_t q, uint32_t& i, uint
             pl = (tile << 6) + (rem & 63u);
             slot = tile * tileSpan + rem;
         } else {
+            RT_SITE(K_PARTIAL);
             const uint32_t rem = q - nFull * tileSpan;
             const uint32_t wl = p.npix_local - (nFull << 6);
             k = rem / wl;
@@ -245,6 +247,7 @@ RT_DEV void mark_dry(SceneConsts* ldsK, uint32_t lane, uint32_t k) {
 }
 RT_DEV bool claim_block(const TraceParams& p, SceneConsts* ldsK, uint32_t lane, uint32_t qb, uint32_t& blkNext, uint32_t& blkEnd,
                         uint32_t& shard) {
+    RT_SITE(K_CLAIM);
     uint32_t dry = dry_shards(ldsK);
     for (uint32_t a = 0; a < kQueueShards; ++a) {
         const uint32_t k = (blockIdx.x + a) & (kQueueShards - 1u);
@@ -304,6 +307,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz; diagnostic build only
     uint32_t tlCarriedIn = 0;
 #endif
+    RT_SITE(K_WAVE);
     extern __shared__ float4 smem[];
     // [0, kConstBytes): the scene constants; then the per-wave regions; then the tables
     SceneConsts* ldsK = reinterpret_cast<SceneConsts*>(smem);
@@ -424,6 +428,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     // C2) ran under the work on a whole block instead of stalling the wave.  A claim that came back beyond the shard's end
     // falls through to a fresh look.
     auto nextBlock = [&]() -> bool {
+        RT_SITE(K_NEXTBLOCK);
         bool got = false;
         if (pendShard < kQueueShards) {
             const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)pendCount);
@@ -446,6 +451,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     };
     // A finished path: GetHitColor * exposureAdjustment, spheres-app.cpp:183; one 12-byte store
     auto finishPath = [&]() {
+        RT_SITE(K_FINISH);
         const float expo = K.exposure;
         *reinterpret_cast<float3*>(p.samples + (size_t)q * 3) = make_float3(rad.x * expo, rad.y * expo, rad.z * expo);
         if (p.trav_out) p.trav_out[q] = pathTrav;
@@ -463,6 +469,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
     // Hit processing of one closest hit (scan entry idx at pos) for a lane in state kNeedClosest: Scatter, the shadow
     // query, Emit + Shade, and the path's next state (GetHitColor, spheres-app.cpp:238-257).
     auto processHit = [&](int idx, V3 pos, bool& finished) {
+        RT_SITE(H_PROCESS);
         const float4 S = scanTab[idx];
         const float radius = radTab[idx];  // radius and material tables are in scan-entry (clustered) order
         const Mat m = load_material(matTab, idx);
@@ -488,6 +495,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         RT_ACC(cyHit[1], th1, th2);
         RT_ACC(cyHit[2], th2, th3);
         if (useIndex) {
+            RT_SITE(H_INDEXED);
             // shadow ray answered by the exact footprint index: no second scan for this hit
             ++nTrav;  // the shadow ray still counts as a traversal of the scene (matches the oracle's counter)
             ++pathTrav;
@@ -502,6 +510,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                 finished = true;
             }
         } else {
+            RT_SITE(H_FARHIT);
             pend = thr * local;
             // a path that does not scatter ends here, so its nextDir registers carry throughput * (Emit + 0),
             // the value the reference adds when the sun is occluded (0 for every non-emissive material)
@@ -515,6 +524,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         }
     };
     for (;;) {
+        RT_SITE(K_ITER);
         RT_STAMP(ts0);
         // ------------------------------------------------ refill idle lanes (ballot + prefix)
         // New paths come from a per-wave cache of 64 prepared paths in LDS: when it runs empty ALL 64 lanes generate
@@ -528,10 +538,12 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
             const uint32_t cap = p.stash_cap;  // <= 63 records of kStashDwords dwords
             // (1) idle lanes take stashed hits (newest first)
             if (stashCnt != 0u && idleMask != 0ull) {
+                RT_SITE(K_POP);
                 const uint32_t nIdle = (uint32_t)__popcll(idleMask);
                 const uint32_t n = stashCnt < nIdle ? stashCnt : nIdle;
                 const uint32_t r = prefix_count(idleMask);
                 if (state == kIdle && r < n) {
+                    RT_SITE(K_POP_LANE);
                     const float* e = stash + (stashCnt - 1u - r);
                     ro = v3(e[0], e[cap], e[2u * cap]);
                     rd = v3(e[3u * cap], e[4u * cap], e[5u * cap]);
@@ -555,10 +567,12 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                 if (blkNext == blkEnd) {
                     process = true;  // no fresh paths left: the hits are processed as they are
                 } else {
+                    RT_SITE(K_PUSH);
                     // (the stash is empty here: had records been left after (1), no lane would be idle, so with nothing to
                     // scan all 64 would hold a hit)
                     wave_lds_handoff();  // the pops above have read their records
                     if (state == kHaveHit) {
+                        RT_SITE(K_PUSH_LANE);
                         float* e = stash + prefix_count(hitMask);
                         e[0] = ro.x; e[cap] = ro.y; e[2u * cap] = ro.z;
                         e[3u * cap] = rd.x; e[4u * cap] = rd.y; e[5u * cap] = rd.z;
@@ -576,6 +590,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                 }
             }
             if (process) {
+                RT_SITE(K_PROCESS);
                 bool finished = false;
                 if (state == kHaveHit) {
                     const int hidx = (int)(depth >> 16);
@@ -591,6 +606,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
             if (__ballot(state != kIdle) == 0ull) {
                 if (blkNext == blkEnd && !queueEmpty && !nextBlock()) queueEmpty = true;
                 if (blkNext != blkEnd) {
+                    RT_SITE(K_GEN);
 #ifdef RT_TIMELINE
                     if (blkNext % kBlk == 0u) {
                         tlLastClaim = __builtin_amdgcn_s_memrealtime();
@@ -600,6 +616,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
 #endif
                     const uint32_t nGen = (blkEnd - blkNext) < (uint32_t)kWaveSize ? (blkEnd - blkNext) : (uint32_t)kWaveSize;
                     if (lane < nGen) {
+                        RT_SITE(K_GEN_LANE);
                         uint32_t i, j, sN;
                         path_coordinates(p, blkNext + lane, i, j, sN, q);
                         draws.rng = rng_seed(p.seed, j * p.W + i, sN);
@@ -783,11 +800,13 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         if (state == kNeedClosest) {
             ++nSeg;
             if (idx < 0) {
+                RT_SITE(K_TRANS_MISS);
                 // miss: sky Emissive::Emit (spheres-app.cpp:255)
                 const V3 sky = v3(K.sky_emit[0], K.sky_emit[1], K.sky_emit[2]);
                 rad = rad + thr * sky;
                 finished = true;
             } else if (kStash) {
+                RT_SITE(K_TRANS_HIT);
                 // the hit waits for a full wave of hits: position (XMVectorMultiplyAdd(t, dir, origin), ray-tracing.cpp:57) in
                 // place of the origin, scan entry beside the depth
                 ro = tmin * rd + ro;
@@ -797,6 +816,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
                 processHit(idx, tmin * rd + ro, finished);  // XMVectorMultiplyAdd(t, dir, origin), ray-tracing.cpp:57
             }
         } else if (state == kNeedShadow) {
+            RT_SITE(K_TRANS_SHADOW);
             if (idx < 0) rad = rad + pend;              // sun visible: radiance += throughput * (Emit + Shade)
             else if (!pathScattered) rad = rad + nextDir;  // occluded: radiance += throughput * (Emit + 0)
             if (contAfterShadow) {

@@ -282,6 +282,7 @@ RT_DEV void gen_primary_ray(const P& p, uint32_t i, uint32_t j, uint32_t s, V3& 
         const GlobalF lt = (GlobalF)(p.lens_tab + (li - p.lens_k0));
         jx = jt[0]; jy = jt[1]; lensx = lt[0]; lensy = lt[1];
     } else {
+        RT_SITE(P_HALTON);
         jx = halton(s, 2);
         jy = halton(s, 3);
         halton_disk_4_5(li, lensx, lensy, p.sampler);

@@ -388,6 +388,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                            const float* __restrict__ ops, uint32_t nTiles,
                            uint32_t nTop, const float4* __restrict__ tree, const uint32_t* levelOff, uint32_t nLevels, float boundNorm,
                            const unsigned long long* singleMask, uint32_t nAlways, const float* treeBox, V3 o, V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand, uint32_t lane, unsigned long long* dbg) {
+    RT_SITE(S_SCAN);
     const float a = dot3(d, d);
     tmin = __builtin_inff();
     idx = -1;
@@ -434,6 +435,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
     // *a = tiles 0,1, *b = tiles 2,3 (all ones = nothing to resolve when the image has only two tiles)
     uint32_t w0a = 0xffffffffu, w1a = 0xffffffffu, w0b = 0xffffffffu, w1b = 0xffffffffu;
     for (uint32_t sp = 0; sp < nTiles; sp += 2) {
+        RT_SITE(S_TILEPAIR);
         uint32_t r0 = 0u, r1 = 0u;
 #pragma unroll
         for (uint32_t k = 0; k < 2; ++k) {
@@ -497,17 +499,20 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
             const uint32_t inclS = wave_inclusive_sum(nS);
             const uint32_t totalS = (uint32_t)__builtin_amdgcn_readlane((int)inclS, 63);
             if (totalS != 0u && totalS <= kPoolB - 4u * kWaveSize) {  // (more than that: they take the ordinary way)
+                RT_SITE(S_SINGLE);
                 cur &= ~sCur;
                 nxt &= ~sNxt;
                 uint16_t* wp = poolB + (inclS - nS);
                 const uint32_t tag = lane << 10;
                 unsigned long long m0 = sCur, m1 = sNxt;
                 while (m0 != 0ull) {
+                    RT_SITE(S_SINGLE_PUSH0);
                     const uint32_t N = (uint32_t)__builtin_clzll(m0);
                     m0 &= ~(0x8000000000000000ull >> N);
                     *wp++ = (uint16_t)(tag | (4u * (N + (N & 48u))));
                 }
                 while (m1 != 0ull) {
+                    RT_SITE(S_SINGLE_PUSH1);
                     const uint32_t N = (uint32_t)__builtin_clzll(m1);
                     m1 &= ~(0x8000000000000000ull >> N);
                     *wp++ = (uint16_t)(tag | (4u * (16u + N + (N & 48u))));
@@ -520,8 +525,10 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
         RT_STAMP(ta0);
         // phase B over the current contents of poolB (wave-uniform count)
         auto drainB = [&]() {
+            RT_SITE(S_DRAIN);
             wave_lds_handoff();  // poolB entries written by other lanes
             for (uint32_t base = 0; base < cntB; base += kWaveSize) {
+                RT_SITE(S_BSTEP);
                 const uint32_t k = base + lane;
                 const bool has = k < cntB;
                 const uint32_t ent = has ? (uint32_t)poolB[k] : 0u;
@@ -544,6 +551,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                 if (!(t > 0.001f)) t = (-b + sq) / ra;  // :69
                 // `e > 0` is the reference's own test (ray-tracing.cpp:54); `t < inf` is the scan's initial tmin
                 if (has && e > 0.f && t > 0.001f && t < __builtin_inff()) {
+                    RT_SITE(S_BMIN);
                     const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((orig[cand] << 16) | cand);
                     __hip_atomic_fetch_min(best + r, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
@@ -552,6 +560,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
             wave_lds_handoff();  // poolB may be refilled from here on
         };
         while (__ballot(pending) != 0ull) {
+            RT_SITE(S_PASS);
             // lanes whose items fit into the list this pass: a prefix of the pending lanes
             const uint32_t incl = wave_inclusive_sum(pending ? nMine : 0u);
             const bool take = pending && incl <= kPoolA;
@@ -559,15 +568,18 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
             const uint32_t lastLane = 63u - (uint32_t)__builtin_clzll(takeMask);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)lastLane);
             if (take) {
+                RT_SITE(S_TAKE);
                 // one loop per bitmap half (leading-zero order; bit N of half h is group 16 h + N + (N & 48))
                 uint16_t* wp = poolA + (incl - nMine);
                 const uint32_t tag = lane << 7;
                 while (cur != 0ull) {
+                    RT_SITE(S_TAKE_PUSH0);
                     const uint32_t N = (uint32_t)__builtin_clzll(cur);
                     cur &= ~(0x8000000000000000ull >> N);
                     *wp++ = (uint16_t)(tag | (N + (N & 48u)));
                 }
                 while (nxt != 0ull) {
+                    RT_SITE(S_TAKE_PUSH1);
                     const uint32_t N = (uint32_t)__builtin_clzll(nxt);
                     nxt &= ~(0x8000000000000000ull >> N);
                     *wp++ = (uint16_t)(tag | (16u + N + (N & 48u)));
@@ -576,6 +588,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
             }
             wave_lds_handoff();  // poolA items written by their owner lanes, read by any lane
             for (uint32_t base = 0; base < total; base += kWaveSize) {
+                RT_SITE(S_ASTEP);
 #ifdef RT_STAMPS
                 dbg[6] += 1;
 #endif
@@ -599,6 +612,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                     uint16_t* wp = poolB + cntB + (incl - nh);
                     uint32_t mm = m;
                     while (mm != 0u) {
+                        RT_SITE(S_APUSH);
                         const uint32_t bit = 31u - (uint32_t)__builtin_clz(mm);
                         mm &= ~(1u << bit);
                         *wp++ = (uint16_t)(r << 10 | (4u * gid + (3u - bit)));
@@ -904,6 +918,7 @@ RT_DEV void grid_slab_rows(float su, float sv, float eu, float ev, float D, floa
 RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restrict__ leaf, const uint32_t* __restrict__ orig,
                            const GridParams G, const uint16_t* __restrict__ cellStart, uint32_t nAlways, const float* treeBox, float boundNorm,
                            V3 o, V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand, uint32_t lane) {
+    RT_SITE(G_SCAN);
     const float a = dot3(d, d);
     tmin = __builtin_inff();
     idx = -1;
@@ -961,8 +976,10 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
         }
     }
     auto drainExact = [&]() {
+        RT_SITE(G_DRAIN);
         wave_lds_handoff();  // exact-list entries written by other lanes
         for (uint32_t base = 0; base < nExact; base += kWaveSize) {
+            RT_SITE(G_BSTEP);
             const uint32_t k = base + lane;
             const bool has = k < nExact;
             const uint32_t ent = has ? exact[k] : 0u;
@@ -981,6 +998,7 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
             float t = (-b - sq) / ra;               // ray-tracing.cpp:56
             if (!(t > 0.001f)) t = (-b + sq) / ra;  // :69
             if (has && e > 0.f && t > 0.001f && t < __builtin_inff()) {
+                RT_SITE(G_BMIN);
                 const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((orig[cand] << 16) | cand);
                 __hip_atomic_fetch_min(best + r, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -993,6 +1011,7 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
     // first far limits.
     const float btBig = 1e-4f * __builtin_sqrtf(a) * (__builtin_sqrtf(oo) + G.bigNorm);
     for (uint32_t q = 0; q < nAlways; ++q) {
+        RT_SITE(G_BIG);
         if (nExact + (uint32_t)kWaveSize > kTreeExact) drainExact();
         const bool cand = live && bound_rejected(leaf[4u * q], v3(gx, gy, gz), d, a, dO, crLeaf, btBig) >= 0;
         const uint64_t lm = __ballot(cand);
@@ -1010,8 +1029,10 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
         // feed: every ray with slabs left lists its next (up to) kFeed of them, front to back -- (ray, slab) is all an item says;
         // a ray whose next slab begins beyond its closest hit so far is done
         while (nWork + 64u * kFeed <= kTreeWork && __ballot(pending) != 0ull) {
+            RT_SITE(G_FEED);
             uint32_t cnt = 0;
             if (pending) {
+                RT_SITE(G_FEED_LANE);
                 const uint32_t left = (uint32_t)((slabLast - slab) * slabStep) + 1u;
                 cnt = left < kFeed ? left : kFeed;
                 const uint32_t tb = reinterpret_cast<const uint32_t*>(best + lane)[1];
@@ -1038,6 +1059,7 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
         wave_lds_handoff();  // items listed by other lanes
         // consume the whole list in the order it was fed: 64 (ray, slab) items per round
         for (uint32_t base = 0; base < nWork; base += kWaveSize) {
+            RT_SITE(G_ROUND);
             const bool has = base + lane < nWork;
             const uint32_t ent = has ? work[base + lane] : 0u;
             const uint32_t r = ent >> 8;
@@ -1063,6 +1085,7 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
             }
             // four spheres per step; every lane runs as many steps as the longest run of the round needs
             while (__ballot(eb < ee) != 0ull) {
+                RT_SITE(G_STEP);
                 const uint32_t tbits = reinterpret_cast<const uint32_t*>(best + r)[1];  // far limit: the ray's closest hit so far
                 float fu = tbits < 0x7f800000u ? (fa * __uint_as_float(tbits)) * (1.f + 0x1p-10f) : __builtin_inff();
                 fu = __builtin_fminf(fu, fuf);
@@ -1083,6 +1106,7 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
                     uint32_t* wp = exact + nExact + (incl - nh);
                     uint32_t mm = m;
                     while (mm != 0u) {
+                        RT_SITE(G_PUSH);
                         const uint32_t bit = 31u - (uint32_t)__builtin_clz(mm);
                         mm &= ~(1u << bit);
                         *wp++ = r << 16 | (eb + (3u - bit));

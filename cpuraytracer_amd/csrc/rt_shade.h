@@ -57,6 +57,7 @@ struct ScriptedDraws {
 template <class Draws>
 RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V3& outDir, V3& tex, const MathTabs& mt = default_math_tabs(),
                          uint32_t sampler = 0u) {
+    RT_SITE(H_SCATTER);
     const float uvx = 0.5f * nrm.x + 0.5f;  // Sphere::ComputeUV, ray-tracing.cpp:26-40
     const float uvy = 0.5f * nrm.z + 0.5f;
     tex = eval_texture(m, uvx, uvy);
@@ -70,6 +71,7 @@ RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V
     const float ndv = dot3(-rd, nrm);  // material.cpp:22,74
 
     if (m.type == RT_MAT_DIELECTRIC_TRANSPARENT) {  // material.cpp:111-164
+        RT_SITE(H_TRANSPARENT);
         const float dn = dot3(rd, nrm);
         V3 outwardNormal;
         float niOverNt, cosI;
@@ -89,6 +91,7 @@ RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V
         raw = prob > u ? mirror : refr;
         scattered = true;
     } else if (m.type == RT_MAT_METAL) {  // material.cpp:72-103
+        RT_SITE(H_METAL);
         if (ndv > 0.f) {
             // The 4-lane coin (XMVectorGreaterR + AnyTrue) is always true: lane w of f0 is the
             // colour's alpha = 1, so R.w = 1 > u.  The draw is still consumed (material.cpp:82).
@@ -99,6 +102,7 @@ RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V
         }
     } else if (m.type == RT_MAT_DIELECTRIC_OPAQUE) {  // material.cpp:20-65
         if (ndv > 0.f) {
+            RT_SITE(H_OPAQUE);
             const float nDotV = sat1(ndv);
             const float refl = 0.04f + (1.f - 0.04f) * rt_powf(1.f - nDotV, 5.f);
             const float u = draws.next();
@@ -106,6 +110,7 @@ RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V
                 atten = v3(1.f, 1.f, 1.f);
                 raw = mirror;
             } else {
+                RT_SITE(H_OPAQUE_DIFFUSE);
                 atten = tex;
                 const float u1 = draws.next();  // HaltonSampleHemisphere's two dimensions
                 const float u2 = draws.next();
@@ -134,33 +139,36 @@ RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V
 template <class P>
 RT_DEV void shade_value(const P& p, const Mat& m, V3 tex, V3 pos, V3 nrm, bool wantShade, V3& local, V3& localOccluded,
                         const MathTabs& mt = default_math_tabs()) {
+    RT_SITE(H_SHADEV);
     V3 emit = v3(0.f, 0.f, 0.f);
     if (m.type == RT_MAT_EMISSIVE) emit = m.luminance * tex;  // material.cpp:172-175; 0 for every other material
     localOccluded = emit + v3(0.f, 0.f, 0.f);  // Shade returns XM_Zero when the sun is occluded (light.cpp:15-18)
     local = localOccluded;
-    if (!wantShade) return;
-    // Material getters (material.h:26-29,42-45,59-62,76-79)
-    V3 albedo = v3(0.f, 0.f, 0.f), f0 = v3(0.04f, 0.04f, 0.04f);
-    if (m.type == RT_MAT_DIELECTRIC_OPAQUE) albedo = tex;
-    else if (m.type == RT_MAT_METAL) f0 = tex;
-    else if (m.type == RT_MAT_EMISSIVE) f0 = v3(0.f, 0.f, 0.f);
-    const float smooth = (m.type == RT_MAT_EMISSIVE) ? 0.f : m.smoothness;
+    if (wantShade) {
+        RT_SITE(H_SHADE);
+        // Material getters (material.h:26-29,42-45,59-62,76-79)
+        V3 albedo = v3(0.f, 0.f, 0.f), f0 = v3(0.04f, 0.04f, 0.04f);
+        if (m.type == RT_MAT_DIELECTRIC_OPAQUE) albedo = tex;
+        else if (m.type == RT_MAT_METAL) f0 = tex;
+        else if (m.type == RT_MAT_EMISSIVE) f0 = v3(0.f, 0.f, 0.f);
+        const float smooth = (m.type == RT_MAT_EMISSIVE) ? 0.f : m.smoothness;
 
-    // DirectionalLight::Shade, light.cpp:21-40 (viewOrigin is always the camera origin, spheres-app.cpp:250)
-    const V3 L = v3(p.sun_dir[0], p.sun_dir[1], p.sun_dir[2]);
-    const float nDotL = sat1(dot3(nrm, L));
-    const V3 radianceIn = v3(p.sun_rad[0] * nDotL, p.sun_rad[1] * nDotL, p.sun_rad[2] * nDotL);
-    const V3 viewDir = normalize3(v3(p.cam_o[0], p.cam_o[1], p.cam_o[2]) - pos);
-    const V3 halfVector = normalize3(L + viewDir);
-    const float nDotH = sat1(dot3(nrm, halfVector));
-    const float nDotV2 = sat1(dot3(viewDir, nrm));
-    const float p5 = rt_powf(1.f - nDotV2, 5.f);
-    const float ps = rt_powf(nDotH, smooth, mt);
-    const V3 one = v3(1.f, 1.f, 1.f);
-    const V3 reflectance = f0 + (one - f0) * p5;
-    const V3 spec = ((reflectance * 0.125f) * (smooth + 8.f)) * ps;
-    const V3 shade = radianceIn * (albedo + spec);
-    local = emit + shade;
+        // DirectionalLight::Shade, light.cpp:21-40 (viewOrigin is always the camera origin, spheres-app.cpp:250)
+        const V3 L = v3(p.sun_dir[0], p.sun_dir[1], p.sun_dir[2]);
+        const float nDotL = sat1(dot3(nrm, L));
+        const V3 radianceIn = v3(p.sun_rad[0] * nDotL, p.sun_rad[1] * nDotL, p.sun_rad[2] * nDotL);
+        const V3 viewDir = normalize3(v3(p.cam_o[0], p.cam_o[1], p.cam_o[2]) - pos);
+        const V3 halfVector = normalize3(L + viewDir);
+        const float nDotH = sat1(dot3(nrm, halfVector));
+        const float nDotV2 = sat1(dot3(viewDir, nrm));
+        const float p5 = rt_powf(1.f - nDotV2, 5.f);
+        const float ps = rt_powf(nDotH, smooth, mt);
+        const V3 one = v3(1.f, 1.f, 1.f);
+        const V3 reflectance = f0 + (one - f0) * p5;
+        const V3 spec = ((reflectance * 0.125f) * (smooth + 8.f)) * ps;
+        const V3 shade = radianceIn * (albedo + spec);
+        local = emit + shade;
+    }
 }
 
 // Scatter, then Emit + Shade with the sun assumed visible (the scan-based shadow path decides later).
@@ -219,6 +227,7 @@ RT_DEV bool sphere_any_hit(const float4 S, V3 o, V3 d, float a, float ya, bool a
 template <class P>
 RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint16_t* __restrict__ cellStart,
                          const uint16_t* __restrict__ entries, const uint16_t* __restrict__ glob, V3 pos, V3 L, float aL) {
+    RT_SITE(H_SHADOWQ);
     bool occluded = false;
     unsigned long long queue = 0ull;
     uint32_t nq = 0;
@@ -229,53 +238,54 @@ RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint1
     const bool aOk = false;
     const float yaL = 0.f;
 #endif
-#define RT_CONSIDER(ID, SPH)                                                         \
-    {                                                                                \
-        const uint32_t id_ = (ID);                                                   \
-        const float4 S = (SPH);                                                      \
-        const float ocx = pos.x - S.x;                                               \
-        const float ocy = pos.y - S.y;                                               \
-        const float ocz = pos.z - S.z;                                               \
-        const float b = (ocx * L.x + ocy * L.y) + ocz * L.z;                         \
-        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;                \
-        const float disc = b * b - aL * cc;                                          \
-        if (root_possible(disc, b)) {                                                \
-            if (nq < 4u) {                                                           \
-                queue = (queue << 16) | (unsigned long long)id_;                     \
-                ++nq;                                                                \
-            } else {                                                                 \
-                occluded = occluded || sphere_any_hit(S, pos, L, aL, yaL, aOk); /* queue full (rare): evaluate now */ \
-            }                                                                        \
-        }                                                                            \
-    }
+    // (lambdas, not macros: every statement keeps its own source line, which tools/phase_budget.py attributes instructions by)
+    auto consider = [&](uint32_t id, const float4 S) __attribute__((always_inline)) {
+        RT_SITE(H_SQ_CONSIDER);
+        const float ocx = pos.x - S.x;
+        const float ocy = pos.y - S.y;
+        const float ocz = pos.z - S.z;
+        const float b = (ocx * L.x + ocy * L.y) + ocz * L.z;
+        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;
+        const float disc = b * b - aL * cc;
+        if (root_possible(disc, b)) {
+            if (nq < 4u) {
+                queue = (queue << 16) | (unsigned long long)id;
+                ++nq;
+            } else {
+                RT_SITE(H_SQ_FULL);
+                occluded = occluded || sphere_any_hit(S, pos, L, aL, yaL, aOk);  // queue full (rare): evaluate now
+            }
+        }
+    };
     // two entries per round: both ids, then both spheres, are requested together -- one entry at a time costs two LDS round
     // trips back to back (id, then sphere) per entry with nothing to do in between
-#define RT_WALK(LIST, FIRST, END)                                                    \
-    {                                                                                \
-        uint32_t e_ = (FIRST);                                                       \
-        const uint32_t e1_ = (END);                                                  \
-        for (; e_ + 2u <= e1_; e_ += 2u) {                                           \
-            const uint32_t idA = (LIST)[e_], idB = (LIST)[e_ + 1u];                  \
-            const float4 SA = tab[idA], SB = tab[idB];                               \
-            RT_CONSIDER(idA, SA)                                                     \
-            RT_CONSIDER(idB, SB)                                                     \
-        }                                                                            \
-        if (e_ < e1_) {                                                              \
-            const uint32_t idA = (LIST)[e_];                                         \
-            RT_CONSIDER(idA, tab[idA])                                               \
-        }                                                                            \
-    }
-    RT_WALK(glob, 0u, p.sg_nglobal)
+    auto walk = [&](const uint16_t* __restrict__ list, uint32_t first, uint32_t end) __attribute__((always_inline)) {
+        RT_SITE(H_SQ_WALK);
+        uint32_t e = first;
+        for (; e + 2u <= end; e += 2u) {
+            RT_SITE(H_SQ_ROUND);
+            const uint32_t idA = list[e], idB = list[e + 1u];
+            const float4 SA = tab[idA], SB = tab[idB];
+            consider(idA, SA);
+            consider(idB, SB);
+        }
+        if (e < end) {
+            RT_SITE(H_SQ_TAIL1);
+            const uint32_t idA = list[e];
+            consider(idA, tab[idA]);
+        }
+    };
+    walk(glob, 0u, p.sg_nglobal);
     const float u = dot3(pos, v3(p.sg_e1[0], p.sg_e1[1], p.sg_e1[2]));
     const float v = dot3(pos, v3(p.sg_e2[0], p.sg_e2[1], p.sg_e2[2]));
     const float fx = (u - p.sg_u0) * p.sg_inv_cell, fy = (v - p.sg_v0) * p.sg_inv_cell;
     if (fx >= 0.f && fy >= 0.f && fx < (float)p.sg_nx && fy < (float)p.sg_ny) {
+        RT_SITE(H_SQ_CELL);
         const uint32_t c = (uint32_t)fy * p.sg_nx + (uint32_t)fx;
-        RT_WALK(entries, (uint32_t)cellStart[c], (uint32_t)cellStart[c + 1])
+        walk(entries, (uint32_t)cellStart[c], (uint32_t)cellStart[c + 1]);
     }
-#undef RT_WALK
-#undef RT_CONSIDER
     while (nq > 0u && !occluded) {
+        RT_SITE(H_SQ_ROOTS);
         const uint32_t id = (uint32_t)(queue & 0xffffull);
         queue >>= 16;
         --nq;
