@@ -606,7 +606,11 @@ struct ShadowGrid {
     bool enabled = false;
 };
 
-static void BuildShadowGrid(const rt_sphere* sp, const SceneLayout& L, const float sunDir[3], ShadowGrid& G) {
+// maxCells: cells per axis at most.  64 for the scenes whose index is staged into LDS next to the tables (the flat scan: 8-10 KB on
+// the cover scene); 256 for the scenes whose index stays in global memory (cell-grid and hierarchy scans, 10,000-sphere class): at
+// 64 x 64 a query of grid10k walked ~15 spheres -- 7 rounds of two dependent L2 reads -- at 256 x 256 (cells of about one
+// footprint) ~5.
+static void BuildShadowGrid(const rt_sphere* sp, const SceneLayout& L, const float sunDir[3], uint32_t maxCells, ShadowGrid& G) {
     G = ShadowGrid{};
     const double Lx = sunDir[0], Ly = sunDir[1], Lz = sunDir[2];
     const double ln = std::sqrt(Lx * Lx + Ly * Ly + Lz * Lz);
@@ -666,9 +670,9 @@ static void BuildShadowGrid(const rt_sphere* sp, const SceneLayout& L, const flo
     }
     std::nth_element(rhos.begin(), rhos.begin() + rhos.size() / 2, rhos.end());
     const double ext = std::max(hi[0] - lo[0], hi[1] - lo[1]);
-    double cell = std::max(2.0 * rhos[rhos.size() / 2], ext / 64.0);
-    G.nx = (uint32_t)std::min(64.0, std::max(1.0, std::ceil((hi[0] - lo[0]) / cell)));
-    G.ny = (uint32_t)std::min(64.0, std::max(1.0, std::ceil((hi[1] - lo[1]) / cell)));
+    double cell = std::max(2.0 * rhos[rhos.size() / 2], ext / (double)maxCells);
+    G.nx = (uint32_t)std::min((double)maxCells, std::max(1.0, std::ceil((hi[0] - lo[0]) / cell)));
+    G.ny = (uint32_t)std::min((double)maxCells, std::max(1.0, std::ceil((hi[1] - lo[1]) / cell)));
     G.u0 = (float)lo[0];
     G.v0 = (float)lo[1];
     G.invCell = (float)(1.0 / cell);
@@ -699,6 +703,10 @@ static void BuildShadowGrid(const rt_sphere* sp, const SceneLayout& L, const flo
     }
     size_t total = 0;
     for (const auto& c : cells) total += c.size();
+    if (total >= 65535 && maxCells > 64u) {  // too many entries for 16-bit cell starts: the coarser grid
+        BuildShadowGrid(sp, L, sunDir, maxCells / 2u, G);
+        return;
+    }
     if (total >= 65535 || G.global.size() > 64) return;  // pathological: keep the scan
     G.cellStart.resize(ncell + 1);
     G.entries.reserve(total);
@@ -733,8 +741,10 @@ static TraceVariant ChooseVariant(const rt_ctx* ctx, const rtd::TraceParams& tp)
     V.tree = ctx->useMfma && !V.grid && tp.n_levels > 1;  // deeper hierarchy: tables stay in global memory (L2)
     const uint32_t topCnt = tp.level_cnt[tp.n_levels - 1];
     // the scene constants' slot comes first in the image, then the per-wave regions
-    V.candBytes = rtd::kConstBytes + (size_t)wavesPerBlock * ((V.tree || V.grid) ? rtd::kWaveCandBytes : rtd::kWaveListBytes);
-    V.leafBytes = (size_t)tp.n_padded * 16;  // one-sphere bounds, staged next to the scan table by the flat scan
+    V.candBytes = rtd::kConstBytes + (size_t)wavesPerBlock * ((V.tree || V.grid) ? rtd::kWaveCandBytes : rtd::kWaveListBytes) +
+                  (size_t)tp.sg_glob16 * 16;  // ... and the shadow index's global list in front of the tables (rt_params.h sg_glob_slots)
+    // one-sphere bounds, staged next to the scan table: the flat scan's copy has kFlatLeafStride float4 per group (rt_scan.h), the grid's is dense
+    V.leafBytes = (size_t)(tp.n_padded / 4u) * (V.grid ? 4u : rtd::kFlatLeafStride) * 16;
     V.flat = !V.tree && !V.grid && useLds && ctx->useMfma && (V.candBytes + lds + V.leafBytes + MfmaOpsBytesFor(topCnt)) <= 160 * 1024;
     V.ldsTables = useLds && !V.tree && !V.grid;
     // a grid scene whose tables all fit LDS next to the grid scan's work lists (small scenes laid out for the grid: RT_GRID=2)
@@ -778,6 +788,7 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     tp.fd_w = rtd::make_fastdiv(tp.W ? tp.W : 1u);
     tp.fd_rows = rtd::make_fastdiv(tp.rs.block_rows ? tp.rs.block_rows : 1u);
     tp.mats_in_lds = ctx->matsInLds ? 1u : 0u;
+    tp.sg_glob16 = tp.sg_enabled ? rtd::sg_glob_slots(tp.sg_nglobal) : 0u;
     const size_t lds = LdsBytesFor(tp.n, tp.n_padded, ctx->matsInLds);
     if (tp.n_padded >= 65536) return Fail(RT_ERR_INVALID_ARG, "scenes beyond 65,000 spheres are not supported by the 16-bit candidate lists");
     const uint32_t maxBlocks = (uint32_t)ctx->cuCount * ctx->blocksPerCu;
@@ -1335,7 +1346,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     }
 
     ShadowGrid SG;
-    if (ctx->useShadowGrid) BuildShadowGrid(spheres, L, sun->direction, SG);
+    if (ctx->useShadowGrid) BuildShadowGrid(spheres, L, sun->direction, (L.gridOn || L.nLevels > 1) ? EnvU32("RT_SHADOW_CELLS", 256u) : 64u, SG);
     if (SG.enabled) {
         if ((rc = ctx->sgCells.Reserve(SG.cellStart.size())) != RT_OK) return rc;
         if ((rc = ctx->sgEntries.Reserve(SG.entries.size() + 1)) != RT_OK) return rc;

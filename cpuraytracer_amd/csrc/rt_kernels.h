@@ -137,7 +137,9 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
         float4* ldsScan = tabBase;
         float4* ldsLeaf = ldsScan + p.n_padded;
         constexpr bool kLeafLds = kScan == 1 || kScan == 3;  // the scans that test one-sphere bounds from LDS
-        uint32_t* ldsOrig = reinterpret_cast<uint32_t*>(ldsLeaf + (kLeafLds ? p.n_padded : 0u));
+        // (the flat scan keeps the bounds at kFlatLeafStride float4 per group of four: rt_scan.h)
+        constexpr uint32_t kLeafStride = kScan == 1 ? kFlatLeafStride : 4u;
+        uint32_t* ldsOrig = reinterpret_cast<uint32_t*>(ldsLeaf + (kLeafLds ? (p.n_padded / 4u) * kLeafStride : 0u));
         float4* ldsMat = reinterpret_cast<float4*>(ldsOrig + p.n_padded);  // n_padded is a multiple of 4
         const uint32_t nMatLds = kMatsL2 ? 0u : ((kHitLds || p.mats_in_lds) ? p.n_padded : 0u);
         float* ldsRad = reinterpret_cast<float*>(ldsMat + (size_t)nMatLds * 3);
@@ -145,7 +147,7 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
         for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) {
             ldsScan[k] = p.scan[k];
             ldsOrig[k] = p.orig[k];
-            if (kLeafLds) ldsLeaf[k] = p.leaf[k];
+            if (kLeafLds) ldsLeaf[(k >> 2) * kLeafStride + (k & 3u)] = p.leaf[k];
         }
         for (uint32_t k = threadIdx.x; k < nMatLds * 3; k += blockDim.x) ldsMat[k] = gMat[k];
         for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) ldsRad[k] = p.radius[k];
@@ -326,7 +328,16 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
 #endif
     uint16_t* candBase = reinterpret_cast<uint16_t*>(smem + kConstBytes / 16);
     constexpr uint32_t kWaveRegion = kScan >= 2 ? kWaveCandBytes : kWaveListBytes;  // the work lists of the hierarchy and grid scans
-    float4* tabBase = smem + kConstBytes / 16 + (kThreads / kWaveSize) * (kWaveRegion / 16);
+    // the shadow index's global list (rt_params.h sg_glob_slots): spheres, then ids, in front of the tables
+    float4* globSph = smem + kConstBytes / 16 + (kThreads / kWaveSize) * (kWaveRegion / 16);
+    uint16_t* globIds = reinterpret_cast<uint16_t*>(globSph + p.sg_nglobal);
+    if (p.sg_glob16 != 0u)
+        for (uint32_t k = threadIdx.x; k < p.sg_nglobal; k += blockDim.x) {
+            const uint32_t id = p.sg_global[k];
+            globSph[k] = p.scan[id];
+            globIds[k] = (uint16_t)id;
+        }
+    float4* tabBase = globSph + p.sg_glob16;
     SceneTabs T;
     stage_scene<kLds, kScan, kHitLds, kMatsL2, kSgLds>(p, tabBase, T);  // ends with a workgroup barrier when it staged anything
     const float4* scanTab = T.scan;
@@ -482,7 +493,7 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         const bool cont = (depth < p.max_depth) && scattered;  // spheres-app.cpp:247
         const bool useIndex = K.sg_enabled && dot3(pos, pos) <= K.sg_p0sq;
         bool occluded = false;
-        if (useIndex) occluded = shadow_query(K, scanTab, sgCell, sgEntries, sgGlobal, pos, sunDir, aSun);
+        if (useIndex) occluded = shadow_query(K, scanTab, sgCell, sgEntries, sgGlobal, p.sg_glob16 != 0u, globSph, globIds, pos, sunDir, aSun);
         RT_STAMP(th2);
         // the Blinn-Phong value (two normalisations, two pows) is only needed when the sun is visible or unknown
         shade_value(K, m, tex, pos, nrm, !occluded, local, localOcc, mt);

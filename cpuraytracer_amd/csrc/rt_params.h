@@ -102,6 +102,10 @@ struct FrameCtl {            // device control block of one context's pipeline
     uint32_t committed_samples[2];  // samples per pixel in the HDR strip
 };
 constexpr uint32_t kMaxFramesInFlight = 16;  // regions of the sample ring
+// The shadow index's GLOBAL list (spheres whose footprint covers much of the grid: the floor, the big spheres; <= 64) is walked by
+// every query: its spheres and ids sit in LDS in every variant -- 18 bytes each -- so that the walk reads them directly instead of
+// chasing id -> sphere through the tables (two dependent L2 reads per pair of entries in the large-scene variants).
+RT_DEV uint32_t sg_glob_slots(uint32_t nGlobal) { return nGlobal ? nGlobal + (nGlobal * 2u + 15u) / 16u : 0u; }
 
 struct TraceParams {
     // scene
@@ -140,6 +144,7 @@ struct TraceParams {
     const uint16_t* sg_entries;     // clustered entry indices per cell
     const uint16_t* sg_global;      // entries tested for every query (footprints covering much of the grid)
     uint32_t sg_nx, sg_ny, sg_nglobal, sg_nentries, sg_enabled, sg_in_lds;
+    uint32_t sg_glob16;             // float4 slots of the global list's LDS copy (spheres, then ids) in front of the tables; 0: none (unit kernels)
     float sg_e1[3], sg_e2[3], sg_u0, sg_v0, sg_inv_cell, sg_p0sq;
     float cam_o[3], cam_x[3], cam_y[3], cam_oip[3];
     float aperture, focal;

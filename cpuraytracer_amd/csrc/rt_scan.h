@@ -211,6 +211,24 @@ constexpr uint32_t kWaveCandBytes = kTreeWork * 4 + kTreeExact * 4 + 64 * 8;  //
 constexpr float kMarginK = 4096.f, kMarginKValu = 2048.f, kMarginKLeaf = 64.f;
 constexpr float kMarginRel = kMarginK * 5.9604645e-8f;                 // K * eps
 constexpr uint32_t kRayCacheBytes = 64 * 48;                            // per-wave cache of prepared paths
+// Flat scan: the LDS copy of the one-sphere bounds keeps each group's four float4 at a stride of FIVE (80 bytes).  Phase A
+// reads bound q of (ray, group) items with one ds_read_b128 per q, which the LDS serves in sets of 16 lanes over 64 banks: at a
+// stride of 64 bytes the bank quad of bound q is (4 gid + q) mod 16 -- four values whatever the groups are, so 16 lanes with
+// different groups collided at least four to a quad (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.21); at 80 bytes it is
+// (5 gid + q) mod 16, which takes all sixteen values.  2 KB of LDS for the cover scene.
+#ifndef RT_LEAF_STRIDE
+#define RT_LEAF_STRIDE 5
+#endif
+constexpr uint32_t kFlatLeafStride = RT_LEAF_STRIDE;
+#ifndef RT_A2
+#define RT_A2 1  // flat scan, pooled phase A: two (ray, group) items per lane and step
+#endif
+#ifndef RT_B2
+#define RT_B2 1  // flat scan, exact phase: two (ray, sphere) pairs per lane and step
+#endif
+#ifndef RT_LIST_WORDS
+#define RT_LIST_WORDS 1  // flat scan: candidate lists are pushed word by word (0: the round-3 loops over 64-bit halves)
+#endif                    // float4 slots per group in the flat scan's LDS copy (4 = dense)
 constexpr uint32_t kOpsPerTile = 8 * 64;                                // dwords of the group operand image per 32-group tile
 
 // Split-bf16 operands.  An f32 value v is carried as h + l with h = bf16(v) and l = bf16(v - h) (both round to
@@ -492,6 +510,42 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
         best[lane] = ~0ull;
         wave_lds_handoff();
         uint32_t cntB = 0;
+#if RT_LIST_WORDS
+        // The candidates as four 32-bit words: bit N (from the top) of word k is group kBase[k] + N + (N & 16), kBase = 0, 64, 16, 80.
+        // Every push loop below walks ONE word (v_ffbh, clear, two operations for the item, the store): a loop over a 64-bit half
+        // ran 14 VALU instructions per candidate of the wave's BUSIEST lane; four word loops run ~6 per candidate of the busiest
+        // lane of each word.
+        uint32_t cw0 = (uint32_t)(cur >> 32), cw1 = (uint32_t)cur, cw2 = (uint32_t)(nxt >> 32), cw3 = (uint32_t)nxt;
+        auto pushWord = [&](uint32_t w, uint32_t tagBase, uint32_t scale, uint16_t*& wp) __attribute__((always_inline)) {
+            while (w != 0u) {
+                RT_SITE(S_PUSH_WORD);
+                const uint32_t N = (uint32_t)__builtin_clz(w);
+                w ^= 0x80000000u >> N;
+                *wp++ = (uint16_t)(tagBase + scale * (N + (N & 16u)));
+            }
+        };
+        {   // Candidate groups of ONE sphere (the floor, the big spheres: a third of all candidates) skip the sphere-level filter:
+            // its only finding would be the sliver between the two margins, and an exact slot costs no more than a filter slot.
+            const uint32_t s0 = cw0 & (uint32_t)(singleMask[0] >> 32), s1 = cw1 & (uint32_t)singleMask[0];
+            const uint32_t s2 = cw2 & (uint32_t)(singleMask[1] >> 32), s3 = cw3 & (uint32_t)singleMask[1];
+            const uint32_t nS = (uint32_t)(__builtin_popcount(s0) + __builtin_popcount(s1) + __builtin_popcount(s2) + __builtin_popcount(s3));
+            const uint32_t inclS = wave_inclusive_sum(nS);
+            const uint32_t totalS = (uint32_t)__builtin_amdgcn_readlane((int)inclS, 63);
+            if (totalS != 0u && totalS <= kPoolB - 4u * kWaveSize) {  // (more than that: they take the ordinary way)
+                RT_SITE(S_SINGLE);
+                cw0 ^= s0; cw1 ^= s1; cw2 ^= s2; cw3 ^= s3;
+                uint16_t* wp = poolB + (inclS - nS);
+                const uint32_t tag = lane << 10;  // entry = ray << 10 | scan entry, scan entry = 4 * group
+                pushWord(s0, tag, 4u, wp);
+                pushWord(s1, tag + 4u * 64u, 4u, wp);
+                pushWord(s2, tag + 4u * 16u, 4u, wp);
+                pushWord(s3, tag + 4u * 80u, 4u, wp);
+                cntB = totalS;
+            }
+        }
+        const uint32_t nMine = (uint32_t)(__builtin_popcount(cw0) + __builtin_popcount(cw1) + __builtin_popcount(cw2) + __builtin_popcount(cw3));
+        bool pending = nMine != 0u;
+#else
         {   // Candidate groups of ONE sphere (the floor, the big spheres: a third of all candidates) skip the sphere-level filter:
             // its only finding would be the sliver between the two margins, and an exact slot costs no more than a filter slot.
             const unsigned long long sCur = cur & singleMask[0], sNxt = nxt & singleMask[1];
@@ -522,8 +576,53 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
         }
         const uint32_t nMine = (uint32_t)(__popcll(cur) + __popcll(nxt));
         bool pending = nMine != 0u;
+#endif
         RT_STAMP(ta0);
         // phase B over the current contents of poolB (wave-uniform count)
+#if RT_B2
+        auto drainB = [&]() {
+            RT_SITE(S_DRAIN);
+            wave_lds_handoff();  // poolB entries written by other lanes
+            auto exactPair = [&](uint32_t ent, bool has) __attribute__((always_inline)) {
+                const uint32_t r = ent >> 10, cand = ent & 1023u;
+                const float rox = lane_fetch(r, o.x), roy = lane_fetch(r, o.y), roz = lane_fetch(r, o.z);
+                const float rdx = lane_fetch(r, d.x), rdy = lane_fetch(r, d.y), rdz = lane_fetch(r, d.z);
+                const float ra = lane_fetch(r, a);
+                const float4 S = tab[cand];
+                const float ocx = rox - S.x;
+                const float ocy = roy - S.y;
+                const float ocz = roz - S.z;
+                const float b = (ocx * rdx + ocy * rdy) + ocz * rdz;
+                const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;
+                const float e = b * b - ra * cc;
+                const float sq = __builtin_sqrtf(e);
+                float t = (-b - sq) / ra;               // ray-tracing.cpp:56
+                if (!(t > 0.001f)) t = (-b + sq) / ra;  // :69
+                // `e > 0` is the reference's own test (ray-tracing.cpp:54); `t < inf` is the scan's initial tmin
+                if (has && e > 0.f && t > 0.001f && t < __builtin_inff()) {
+                    RT_SITE(S_BMIN);
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((orig[cand] << 16) | cand);
+                    __hip_atomic_fetch_min(best + r, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            };
+            for (uint32_t base = 0; base < cntB; base += 2u * kWaveSize) {
+                RT_SITE(S_BSTEP);
+                const uint32_t k0 = base + lane, k1 = k0 + (uint32_t)kWaveSize;
+                const bool has0 = k0 < cntB, has1 = k1 < cntB;
+                const uint32_t ent0 = has0 ? (uint32_t)poolB[k0] : 0u, ent1 = has1 ? (uint32_t)poolB[k1] : 0u;
+#ifdef RT_STAMPS
+                dbg[7] += 1;
+#endif
+                exactPair(ent0, has0);
+                if (base + (uint32_t)kWaveSize < cntB) {  // wave-uniform
+                    RT_SITE(S_BSTEP2);
+                    exactPair(ent1, has1);
+                }
+            }
+            cntB = 0;
+            wave_lds_handoff();  // poolB may be refilled from here on
+        };
+#else
         auto drainB = [&]() {
             RT_SITE(S_DRAIN);
             wave_lds_handoff();  // poolB entries written by other lanes
@@ -559,6 +658,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
             cntB = 0;
             wave_lds_handoff();  // poolB may be refilled from here on
         };
+#endif
         while (__ballot(pending) != 0ull) {
             RT_SITE(S_PASS);
             // lanes whose items fit into the list this pass: a prefix of the pending lanes
@@ -567,6 +667,18 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
             const uint64_t takeMask = __ballot(take);
             const uint32_t lastLane = 63u - (uint32_t)__builtin_clzll(takeMask);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)lastLane);
+#if RT_LIST_WORDS
+            if (take) {
+                RT_SITE(S_TAKE);
+                uint16_t* wp = poolA + (incl - nMine);
+                const uint32_t tag = lane << 7;  // item = ray << 7 | group
+                pushWord(cw0, tag, 1u, wp);
+                pushWord(cw1, tag + 64u, 1u, wp);
+                pushWord(cw2, tag + 16u, 1u, wp);
+                pushWord(cw3, tag + 80u, 1u, wp);
+                pending = false;
+            }
+#else
             if (take) {
                 RT_SITE(S_TAKE);
                 // one loop per bitmap half (leading-zero order; bit N of half h is group 16 h + N + (N & 48))
@@ -586,7 +698,59 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                 }
                 pending = false;
             }
+#endif
             wave_lds_handoff();  // poolA items written by their owner lanes, read by any lane
+#if RT_A2
+            // TWO items per lane and step: the two chains (item -> ray fetch + bounds -> tests) are independent, so their LDS round
+            // trips overlap and a scan takes about half the steps; the survivors of both share one prefix sum.  The exact list
+            // is drained when THIS step's survivors would not fit (no worst-case reserve of 4 x 128 entries).
+            for (uint32_t base = 0; base < total; base += 2u * kWaveSize) {
+                RT_SITE(S_ASTEP);
+#ifdef RT_STAMPS
+                dbg[6] += 1;
+#endif
+                auto testItem = [&](uint32_t item, bool has) __attribute__((always_inline)) -> uint32_t {
+                    const uint32_t r = item >> 7, gid = item & 127u;
+                    const V3 fg = v3(lane_fetch(r, gx), lane_fetch(r, gy), lane_fetch(r, gz));
+                    const V3 fd = v3(lane_fetch(r, d.x), lane_fetch(r, d.y), lane_fetch(r, d.z));
+                    const float fa = lane_fetch(r, a), fdO = lane_fetch(r, dO), fcr = lane_fetch(r, crLeaf), fbt = lane_fetch(r, bt);
+                    const float4* lb = leaf + kFlatLeafStride * gid;
+                    uint32_t rb = 0u;
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q)
+                        rb = __builtin_amdgcn_alignbit(rb, (uint32_t)bound_rejected(lb[q], fg, fd, fa, fdO, fcr, fbt), 31);
+                    return has ? (~rb & 15u) : 0u;  // bit 3-q = sphere q of the group
+                };
+                const uint32_t k0 = base + lane, k1 = k0 + (uint32_t)kWaveSize;
+                const bool has0 = k0 < total, has1 = k1 < total;
+                const uint32_t item0 = has0 ? (uint32_t)poolA[k0] : 0u;
+                const bool second = base + (uint32_t)kWaveSize < total;  // wave-uniform: a last, short step tests one item per lane
+                const uint32_t item1 = has1 ? (uint32_t)poolA[k1] : 0u;
+                const uint32_t m0 = testItem(item0, has0);
+                uint32_t m1 = 0u;
+                if (second) {
+                    RT_SITE(S_ASTEP2);
+                    m1 = testItem(item1, has1);
+                }
+                const uint32_t nh = (uint32_t)(__builtin_popcount(m0) + __builtin_popcount(m1));
+                const uint32_t incl = wave_inclusive_sum(nh);
+                const uint32_t totalH = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (cntB + totalH > kPoolB) drainB();  // (totalH <= 512 = kPoolB: fits an empty list)
+                uint16_t* wp = poolB + cntB + (incl - nh);
+                auto pushSurvivors = [&](uint32_t mm, uint32_t item) __attribute__((always_inline)) {
+                    const uint32_t tagEntry = (item >> 7) << 10 | (4u * (item & 127u) + 3u);
+                    while (mm != 0u) {
+                        RT_SITE(S_APUSH);
+                        const uint32_t bit = 31u - (uint32_t)__builtin_clz(mm);
+                        mm &= ~(1u << bit);
+                        *wp++ = (uint16_t)(tagEntry - bit);
+                    }
+                };
+                pushSurvivors(m0, item0);
+                pushSurvivors(m1, item1);
+                cntB += totalH;
+            }
+#else
             for (uint32_t base = 0; base < total; base += kWaveSize) {
                 RT_SITE(S_ASTEP);
 #ifdef RT_STAMPS
@@ -599,7 +763,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                 const V3 fg = v3(lane_fetch(r, gx), lane_fetch(r, gy), lane_fetch(r, gz));
                 const V3 fd = v3(lane_fetch(r, d.x), lane_fetch(r, d.y), lane_fetch(r, d.z));
                 const float fa = lane_fetch(r, a), fdO = lane_fetch(r, dO), fcr = lane_fetch(r, crLeaf), fbt = lane_fetch(r, bt);
-                const float4* lb = leaf + 4u * gid;
+                const float4* lb = leaf + kFlatLeafStride * gid;  // (the flat scan's strided LDS copy: stage_scene)
                 uint32_t rb = 0u;
 #pragma unroll
                 for (uint32_t q = 0; q < 4; ++q)
@@ -621,6 +785,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                 }
                 if (cntB > kPoolB - 4u * kWaveSize) drainB();
             }
+#endif
             wave_lds_handoff();  // the next pass overwrites poolA
         }
         RT_STAMP(ta1);
@@ -873,6 +1038,11 @@ struct GridParams {
 // grid10k: 128 (the hierarchy's value) -> 64 +1.5 %, 48 +2.3 %, 32 +3.5 %
 constexpr uint32_t kGridDrain = RT_GRID_DRAIN;
 static_assert(kTreeExact >= kGridDrain + 4 * 64, "a step may add 256 entries to an exact list that holds up to kGridDrain - 1");
+#ifndef RT_GRID_STEP
+#define RT_GRID_STEP 4
+#endif
+constexpr uint32_t kGridStep = RT_GRID_STEP;  // one-sphere bounds a lane tests per step of the grid scan (4 or 8): eight halves the dependent L2 round trips of 5-8-sphere runs
+static_assert(kGridStep == 4u || kGridStep == 8u, "grid step");
 constexpr float kGridSlack = 1e-3f;  // cells: >= 40 x the rounding of a grid coordinate (|coordinate| <= 256 cells, 2^-24 relative)
 
 // The v-range (rows) of slab iu for a segment S -> E in grid coordinates, widened by D: rows [r0, r1] clamped to the grid, or
@@ -988,6 +1158,7 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
             const float rdx = lane_fetch(r, d.x), rdy = lane_fetch(r, d.y), rdz = lane_fetch(r, d.z);
             const float ra = lane_fetch(r, a);
             const float4 S = tab[cand];
+            const uint32_t og = orig[cand];  // (requested WITH the sphere: inside the branch below it was a second dependent L2 read per accepted root)
             const float ocx = rox - S.x;
             const float ocy = roy - S.y;
             const float ocz = roz - S.z;
@@ -999,7 +1170,7 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
             if (!(t > 0.001f)) t = (-b + sq) / ra;  // :69
             if (has && e > 0.f && t > 0.001f && t < __builtin_inff()) {
                 RT_SITE(G_BMIN);
-                const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((orig[cand] << 16) | cand);
+                const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((og << 16) | cand);
                 __hip_atomic_fetch_min(best + r, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
@@ -1091,29 +1262,38 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
                 fu = __builtin_fminf(fu, fuf);
                 uint32_t rb = 0u;
 #pragma unroll
-                for (uint32_t q = 0; q < 4; ++q) {
+                for (uint32_t q = 0; q < kGridStep; ++q) {
                     const uint32_t e = eb + q;
                     const float4 B = leaf[e < ee ? e : 0u];  // (entry 0 is always there; its result is masked)
                     const int rej = e < ee ? bound_rejected_span(B, fg, fd, fa, fdO, fcr, fbt, fun, fu) : -1;
                     rb = __builtin_amdgcn_alignbit(rb, (uint32_t)rej, 31);
                 }
-                const uint32_t m = ~rb & 15u;  // bit 3-q = entry eb + q
+                const uint32_t m = ~rb & ((1u << kGridStep) - 1u);  // bit kGridStep-1-q = entry eb + q
                 if (nExact >= kGridDrain) drainExact();  // early and often: every exact round may pull the far limits in
-                {
-                    const uint32_t nh = (uint32_t)__builtin_popcount(m);
+                // one prefix sum over the lanes' survivor counts, then every lane appends its own entries
+                auto pushSurvivors = [&](uint32_t mask) __attribute__((always_inline)) {
+                    const uint32_t nh = (uint32_t)__builtin_popcount(mask);
                     const uint32_t incl = wave_inclusive_sum(nh);
                     const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    if (kGridStep > 4u && nExact + tot > kTreeExact) drainExact();  // (four per step: the drain above keeps a step's room)
                     uint32_t* wp = exact + nExact + (incl - nh);
-                    uint32_t mm = m;
+                    uint32_t mm = mask;
                     while (mm != 0u) {
                         RT_SITE(G_PUSH);
                         const uint32_t bit = 31u - (uint32_t)__builtin_clz(mm);
                         mm &= ~(1u << bit);
-                        *wp++ = r << 16 | (eb + (3u - bit));
+                        *wp++ = r << 16 | (eb + (kGridStep - 1u - bit));
                     }
                     nExact += tot;
+                };
+                if (kGridStep > 4u && (uint32_t)__popcll(__ballot(m != 0u)) * kGridStep > kTreeExact) {
+                    // (more survivors than the list holds are possible in principle: eight per lane; then the step is pushed in halves)
+                    pushSurvivors(m & 0xf0u);
+                    pushSurvivors(m & 0x0fu);
+                } else {
+                    pushSurvivors(m);
                 }
-                eb += 4u;
+                eb += kGridStep;
             }
         }
         nWork = 0;

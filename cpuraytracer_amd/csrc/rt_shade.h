@@ -226,7 +226,8 @@ RT_DEV bool sphere_any_hit(const float4 S, V3 o, V3 d, float a, float ya, bool a
 // one occludes.  root_possible() is exact, so the answer is the reference's any-hit over the same spheres.
 template <class P>
 RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint16_t* __restrict__ cellStart,
-                         const uint16_t* __restrict__ entries, const uint16_t* __restrict__ glob, V3 pos, V3 L, float aL) {
+                         const uint16_t* __restrict__ entries, const uint16_t* __restrict__ glob, bool globInLds,
+                         const float4* globSph, const uint16_t* globIds, V3 pos, V3 L, float aL) {
     RT_SITE(H_SHADOWQ);
     bool occluded = false;
     unsigned long long queue = 0ull;
@@ -275,7 +276,23 @@ RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint1
             consider(idA, tab[idA]);
         }
     };
-    walk(glob, 0u, p.sg_nglobal);
+    if (globInLds) {
+        // the global list from its LDS copy (rt_params.h sg_glob_slots): spheres and ids read directly, two per round
+        uint32_t k = 0;
+        for (; k + 2u <= p.sg_nglobal; k += 2u) {
+            RT_SITE(H_SQ_GROUND);
+            const float4 SA = globSph[k], SB = globSph[k + 1u];
+            const uint32_t idA = globIds[k], idB = globIds[k + 1u];
+            consider(idA, SA);
+            consider(idB, SB);
+        }
+        if (k < p.sg_nglobal) {
+            RT_SITE(H_SQ_GTAIL);
+            consider(globIds[k], globSph[k]);
+        }
+    } else {
+        walk(glob, 0u, p.sg_nglobal);
+    }
     const float u = dot3(pos, v3(p.sg_e1[0], p.sg_e1[1], p.sg_e1[2]));
     const float v = dot3(pos, v3(p.sg_e2[0], p.sg_e2[1], p.sg_e2[2]));
     const float fx = (u - p.sg_u0) * p.sg_inv_cell, fy = (v - p.sg_v0) * p.sg_inv_cell;

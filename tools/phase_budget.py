@@ -41,7 +41,7 @@ PHASES = collections.OrderedDict([
     ("scan: operand build, bitmap exchange, result read", ["S_SCAN"]),
     ("scan: MFMA + mfma_post", ["S_TILEPAIR"]),
     ("scan: one-sphere groups straight to the exact list", ["S_SINGLE", "S_SINGLE_PUSH0", "S_SINGLE_PUSH1"]),
-    ("scan: pooled (ray, group) list build", ["S_PASS", "S_TAKE", "S_TAKE_PUSH0", "S_TAKE_PUSH1"]),
+    ("scan: pooled (ray, group) list build", ["S_PASS", "S_TAKE", "S_TAKE_PUSH0", "S_TAKE_PUSH1", "S_PUSH_WORD"]),
     ("scan: pooled phase A (ray fetch + four one-sphere bound tests + survivor push)", ["S_ASTEP", "S_APUSH"]),
     ("scan: exact Sphere::Intersect (phase B)", ["S_DRAIN", "S_BSTEP"]),
     ("scan: ds_min_u64 merge", ["S_BMIN"]),
@@ -54,7 +54,7 @@ PHASES = collections.OrderedDict([
     ("transitions (miss / hit record / far-hit shadow state)", ["K_TRANS_MISS", "K_TRANS_HIT", "K_TRANS_SHADOW"]),
     ("hit processing: glue (material load, normal, state update)", ["K_PROCESS", "H_PROCESS", "H_INDEXED", "H_FARHIT"]),
     ("hit processing: scatter_only", ["H_SCATTER", "H_TRANSPARENT", "H_METAL", "H_OPAQUE", "H_OPAQUE_DIFFUSE"]),
-    ("hit processing: shadow_query", ["H_SHADOWQ", "H_SQ_WALK", "H_SQ_CONSIDER", "H_SQ_ROUND", "H_SQ_TAIL1", "H_SQ_CELL", "H_SQ_ROOTS", "H_SQ_FULL"]),
+    ("hit processing: shadow_query", ["H_SHADOWQ", "H_SQ_WALK", "H_SQ_CONSIDER", "H_SQ_GROUND", "H_SQ_GTAIL", "H_SQ_ROUND", "H_SQ_TAIL1", "H_SQ_CELL", "H_SQ_ROOTS", "H_SQ_FULL"]),
     ("hit processing: shade_value", ["H_SHADEV", "H_SHADE"]),
     ("sample store (finishPath)", ["K_FINISH"]),
     ("loop control, refill ballots, exit test", ["K_ITER"]),
@@ -369,8 +369,8 @@ def do_combine(cfg, pmc_path=None):
     if S.get("S_SCAN", {}).get("visits"):
         scans = T - S.get("H_INDEXED", {"lanes": 0})["lanes"]  # scans that ran through the filter (closest hit + far-hit shadow scans)
         ss.update({"ray_scans_through_the_filter": scans, "wave_scans": S["S_SCAN"]["visits"],
-                   "candidate_groups_per_scan": (S["S_TAKE_PUSH0"]["lanes"] + S["S_TAKE_PUSH1"]["lanes"] + S["S_SINGLE_PUSH0"]["lanes"] + S["S_SINGLE_PUSH1"]["lanes"]) / scans,
-                   "one_sphere_groups_per_scan": (S["S_SINGLE_PUSH0"]["lanes"] + S["S_SINGLE_PUSH1"]["lanes"]) / scans,
+                   "candidate_groups_per_scan": sum(S.get(n, {"lanes": 0})["lanes"] for n in ("S_TAKE_PUSH0", "S_TAKE_PUSH1", "S_SINGLE_PUSH0", "S_SINGLE_PUSH1", "S_PUSH_WORD")) / scans,
+                   "push_loop_iterations_per_wave_scan": sum(S.get(n, {"visits": 0})["visits"] for n in ("S_TAKE_PUSH0", "S_TAKE_PUSH1", "S_SINGLE_PUSH0", "S_SINGLE_PUSH1", "S_PUSH_WORD")) / S["S_SCAN"]["visits"],
                    "phase_A_items_per_scan": S["S_ASTEP"]["lanes"] / scans,
                    "phase_A_steps_per_wave_scan": S["S_ASTEP"]["visits"] / S["S_SCAN"]["visits"],
                    "phase_A_lane_utilisation": S["S_ASTEP"]["lanes"] / (64.0 * S["S_ASTEP"]["visits"]),
