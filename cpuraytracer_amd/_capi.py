@@ -86,7 +86,7 @@ def load():
     L.rt_set_frame_pipelining.argtypes = [C.c_void_p, C.c_uint32]
     L.rt_set_frame_batch.argtypes = [C.c_void_p, C.c_uint32]
     L.rt_committed_samples.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
-    L.rt_scene_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(RtCamera), C.POINTER(RtLight),
+    L.rt_scene_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(RtCamera), C.POINTER(RtLight), C.c_uint32,
                                   C.POINTER(RtMaterial), C.c_float]
     L.rt_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, RtRowset, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                             C.POINTER(RtStats)]

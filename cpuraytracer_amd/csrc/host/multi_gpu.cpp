@@ -60,10 +60,10 @@ int RenderMultiGpu(const AppSettingsT& st, int nGpus, uint32_t spp, MultiGpuResu
     std::vector<rt_sphere> spheres;
     std::vector<rt_material> materials;
     rt_camera camera;
-    rt_light sun;
+    std::vector<rt_light> lights;
     rt_material sky;
     float exposure;
-    builder.DescribeScene(spheres, materials, camera, sun, sky, exposure);
+    builder.DescribeScene(spheres, materials, camera, lights, sky, exposure);
 
     std::vector<Rank> ranks(G);
     std::vector<ncclComm_t> comms(G);
@@ -86,7 +86,7 @@ int RenderMultiGpu(const AppSettingsT& st, int nGpus, uint32_t spp, MultiGpuResu
             HIP_OK(hipMemset(rk.hdrStrip, 0, stripPix * 3 * sizeof(float)));
             HIP_OK(hipMemset(rk.ldrStrip, 0, stripPix * 3));
             if (rt_create(rk.device, &rk.ctx) != RT_OK || rt_set_stream(rk.ctx, rk.stream) != RT_OK ||
-                rt_scene_upload(rk.ctx, spheres.data(), materials.data(), (uint32_t)spheres.size(), &camera, &sun, &sky, exposure) != RT_OK ||
+                rt_scene_upload(rk.ctx, spheres.data(), materials.data(), (uint32_t)spheres.size(), &camera, lights.data(), (uint32_t)lights.size(), &sky, exposure) != RT_OK ||
                 rt_set_sampler(rk.ctx, st.samplerFlags) != RT_OK)
                 rk.error = rt_last_error();
         }();

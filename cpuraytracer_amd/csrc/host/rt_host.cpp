@@ -42,7 +42,7 @@ const std::vector<const Material*>& UploadFor(const Hitable* h) {
     const rt_light sun = DummyLight();
     rt_material sky{};
     sky.type = RT_MAT_EMISSIVE;
-    RT_CALL(rt_scene_upload(DeviceEval::Context(), s.data(), m.data(), (uint32_t)s.size(), &cam, &sun, &sky, 1.f));
+    RT_CALL(rt_scene_upload(DeviceEval::Context(), s.data(), m.data(), (uint32_t)s.size(), &cam, &sun, 1u, &sky, 1.f));
     g_sceneOwner = h;
     return owners;
 }

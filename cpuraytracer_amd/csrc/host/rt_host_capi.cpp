@@ -26,10 +26,11 @@ int rth_build_scene(const char* name, uint64_t seed, int width, int height, floa
         std::vector<rt_sphere> s;
         std::vector<rt_material> m;
         rt_camera c;
-        rt_light l;
+        std::vector<rt_light> ls;
         rt_material k;
         float e;
-        app.DescribeScene(s, m, c, l, k, e);
+        app.DescribeScene(s, m, c, ls, k, e);
+        const rt_light l = ls.empty() ? rt_light{} : ls.front();  // (the generators' scenes have one light, spheres-app.cpp:129)
         if (n) *n = (uint32_t)s.size();
         if (s.size() > cap) return 1;
         if (spheres) std::memcpy(spheres, s.data(), s.size() * sizeof(rt_sphere));

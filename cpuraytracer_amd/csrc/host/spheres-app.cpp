@@ -136,13 +136,14 @@ void SpheresApp::InitScene() {  // spheres-app.cpp:51-130
     m_uploaded = false;
 }
 
-void SpheresApp::DescribeScene(std::vector<rt_sphere>& spheres, std::vector<rt_material>& materials, rt_camera& camera, rt_light& sun,
-                               rt_material& sky, float& exposureScale) const {
+void SpheresApp::DescribeScene(std::vector<rt_sphere>& spheres, std::vector<rt_material>& materials, rt_camera& camera,
+                               std::vector<rt_light>& lights, rt_material& sky, float& exposureScale) const {
     spheres.clear();
     materials.clear();
     m_bvh->Flatten(spheres, materials);
     camera = m_camera->Describe();
-    sun = m_lights.front()->Describe();
+    lights.clear();  // every light of the list, in list order (Material::Shade adds them in that order, material.cpp:4-13)
+    for (const auto& l : m_lights) lights.push_back(l->Describe());
     sky = m_skyMaterial->Describe();
     exposureScale = static_cast<float>(std::pow(2, m_exposure));  // spheres-app.cpp:174
 }
@@ -161,11 +162,12 @@ size_t SpheresApp::DrawBitmap() {  // spheres-app.cpp:163-222
         std::vector<rt_sphere> spheres;
         std::vector<rt_material> materials;
         rt_camera camera;
-        rt_light sun;
+        std::vector<rt_light> lights;
         rt_material sky;
         float exposureAdjustment;
-        DescribeScene(spheres, materials, camera, sun, sky, exposureAdjustment);
-        RT_CALL(rt_scene_upload(m_device, spheres.data(), materials.data(), (uint32_t)spheres.size(), &camera, &sun, &sky, exposureAdjustment));
+        DescribeScene(spheres, materials, camera, lights, sky, exposureAdjustment);
+        RT_CALL(rt_scene_upload(m_device, spheres.data(), materials.data(), (uint32_t)spheres.size(), &camera, lights.data(), (uint32_t)lights.size(), &sky,
+                                exposureAdjustment));
         RT_CALL(rt_set_sampler(m_device, AppSettings.samplerFlags));
         RT_CALL(rt_set_frame_pipelining(m_device, AppSettings.framesInFlight));
         RT_CALL(rt_set_frame_batch(m_device, AppSettings.framesPerLaunch ? AppSettings.framesPerLaunch : 1u));

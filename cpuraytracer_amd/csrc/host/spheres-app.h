@@ -56,7 +56,7 @@ public:
     ~SpheresApp() override;
 
     // flat scene as uploaded (for tools / bindings)
-    void DescribeScene(std::vector<rt_sphere>& spheres, std::vector<rt_material>& materials, rt_camera& camera, rt_light& sun,
+    void DescribeScene(std::vector<rt_sphere>& spheres, std::vector<rt_material>& materials, rt_camera& camera, std::vector<rt_light>& lights,
                        rt_material& sky, float& exposureScale) const;
     bool WritePPM(const std::string& path) const;
     const std::vector<XMVECTOR>& Hdr() const { return m_backbufferHdr; }

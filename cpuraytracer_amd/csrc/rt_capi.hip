@@ -93,6 +93,13 @@ struct rt_ctx {
     DevBuf<float4> scan, tree, leaf;
     DevBuf<uint32_t> orig;
     DevBuf<uint16_t> sgCells, sgEntries, sgGlobal;
+    DevBuf<float4> sgSph;  // large scenes: the scan record of every shadow-index entry (rt_params.h sg_sph)
+    // lights 1 .. n_lights-1 (rt_params.h LightRec): their records and their shadow indices, in global memory
+    struct ExtraLight {
+        DevBuf<uint16_t> cells, entries, global;
+    };
+    ExtraLight extraIdx[RT_MAX_LIGHTS];
+    DevBuf<rtd::LightRec> lightRecs;
     DevBuf<uint16_t> gridCells;  // cell-grid scan: first scan entry per cell
     bool useShadowGrid = true;  // RT_SHADOW_GRID=0 keeps every shadow ray on the scan
     DevBuf<float> radius;
@@ -905,21 +912,27 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
         if (carryMode == 1) return ok ? RT_OK : RT_ERR_INVALID_ARG;
         if (!ok) return Fail(RT_ERR_INVALID_ARG, "frame pipelining needs the flat LDS variant of the trace kernel");
     }
-#define RT_LAUNCH_K(KERNEL)                                                                                                   \
+#define RT_LAUNCH_FN(KERNEL)                                                                                                  \
     do {                                                                                                                      \
         const void* fn_ = reinterpret_cast<const void*>(&KERNEL);                                                             \
         /* the attribute belongs to the FUNCTION on this device, not to the context: raised once to what any launch can ask for, never lowered */ \
         if (ldsBytes > 48 * 1024 && RaiseLdsLimit(ctx->device, fn_) != RT_OK) return RT_ERR_HIP;                               \
         hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(ctx->blockThreads), ldsBytes, ctx->stream, tp);                         \
     } while (0)
+/* the variant with these template arguments: the single-light kernel, or its twin over the light list (rt_kernels.h trace_body) */
+#define RT_LAUNCH_K(...)                                                          \
+    do {                                                                          \
+        if (tp.n_lights == 1u) RT_LAUNCH_FN((rtd::rt_trace_kernel<__VA_ARGS__>)); \
+        else RT_LAUNCH_FN((rtd::rt_trace_kernel_lights<__VA_ARGS__>));            \
+    } while (0)
 #define RT_LAUNCH(LDS, T, M)                                                                        \
     do {                                                                                            \
         if (((M) == 1 && hitLds) || ((M) == 2 && tp.tree_in_lds)) {                                 \
-            if (tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<LDS, T, M, true, (M) != 0>));  \
-            else RT_LAUNCH_K((rtd::rt_trace_kernel<LDS, T, M, false, (M) != 0>));                    \
+            if (tp.ray_cache_off16) RT_LAUNCH_K(LDS, T, M, true, (M) != 0);  \
+            else RT_LAUNCH_K(LDS, T, M, false, (M) != 0);                    \
         } else {                                                                                    \
-            if (tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<LDS, T, M, true, false>));    \
-            else RT_LAUNCH_K((rtd::rt_trace_kernel<LDS, T, M, false, false>));                      \
+            if (tp.ray_cache_off16) RT_LAUNCH_K(LDS, T, M, true, false);    \
+            else RT_LAUNCH_K(LDS, T, M, false, false);                      \
         }                                                                                           \
     } while (0)
 #define RT_LAUNCH_T(LDS, M)                                            \
@@ -928,25 +941,25 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
         else if (ctx->blockThreads == 512) RT_LAUNCH(LDS, 512, M);     \
         else RT_LAUNCH(LDS, 256, M);                                   \
     } while (0)
-    if (carryMode == 2) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 1, true, true, true>));
-    else if (gridLds && useStash && tp.grid_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 3, true, true, false, true>));
-    else if (gridLds && tp.grid_in_lds && tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 3, true, true>));
-    else if (gridLds && tp.grid_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 3, false, true>));
-    else if (grid && gridSgLds && useStash && tp.grid_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 3, true, true, false, true, false, true>));
+    if (carryMode == 2) RT_LAUNCH_K(true, 1024, 1, true, true, true);
+    else if (gridLds && useStash && tp.grid_in_lds) RT_LAUNCH_K(true, 1024, 3, true, true, false, true);
+    else if (gridLds && tp.grid_in_lds && tp.ray_cache_off16) RT_LAUNCH_K(true, 1024, 3, true, true);
+    else if (gridLds && tp.grid_in_lds) RT_LAUNCH_K(true, 1024, 3, false, true);
+    else if (grid && gridSgLds && useStash && tp.grid_in_lds) RT_LAUNCH_K(false, 1024, 3, true, true, false, true, false, true);
     else if (grid && gridSgLds) return Fail(RT_ERR_HIP, "internal: the grid variant with the shadow index in LDS needs the hit stash");
-    else if (grid && ctx->blockThreads == 1024 && useStash && tp.grid_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 3, true, true, false, true>));
-    else if (grid && ctx->blockThreads == 1024 && tp.grid_in_lds && tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 3, true, true>));
-    else if (grid && ctx->blockThreads == 1024 && tp.grid_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 3, false, true>));
-    else if (grid && ctx->blockThreads == 1024) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 3, false, false>));
-    else if (grid && ctx->blockThreads == 512 && !tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 512, 3, false, false>));
-    else if (grid && ctx->blockThreads == 512) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 512, 3, true, false>));
-    else if (grid && !tp.ray_cache_off16) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 256, 3, false, false>));
-    else if (grid) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 256, 3, true, false>));
-    else if (useStash && tree && tp.tree_in_lds) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 2, true, true, false, true>));
-    else if (useStash && tree) RT_LAUNCH_K((rtd::rt_trace_kernel<false, 1024, 2, true, false, false, true>));
-    else if (useStash && hitLds && matsL2) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 1, true, true, false, true, true>));
-    else if (useStash && hitLds) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 1, true, true, false, true>));
-    else if (useStash) RT_LAUNCH_K((rtd::rt_trace_kernel<true, 1024, 1, true, false, false, true>));
+    else if (grid && ctx->blockThreads == 1024 && useStash && tp.grid_in_lds) RT_LAUNCH_K(false, 1024, 3, true, true, false, true);
+    else if (grid && ctx->blockThreads == 1024 && tp.grid_in_lds && tp.ray_cache_off16) RT_LAUNCH_K(false, 1024, 3, true, true);
+    else if (grid && ctx->blockThreads == 1024 && tp.grid_in_lds) RT_LAUNCH_K(false, 1024, 3, false, true);
+    else if (grid && ctx->blockThreads == 1024) RT_LAUNCH_K(false, 1024, 3, false, false);
+    else if (grid && ctx->blockThreads == 512 && !tp.ray_cache_off16) RT_LAUNCH_K(false, 512, 3, false, false);
+    else if (grid && ctx->blockThreads == 512) RT_LAUNCH_K(false, 512, 3, true, false);
+    else if (grid && !tp.ray_cache_off16) RT_LAUNCH_K(false, 256, 3, false, false);
+    else if (grid) RT_LAUNCH_K(false, 256, 3, true, false);
+    else if (useStash && tree && tp.tree_in_lds) RT_LAUNCH_K(false, 1024, 2, true, true, false, true);
+    else if (useStash && tree) RT_LAUNCH_K(false, 1024, 2, true, false, false, true);
+    else if (useStash && hitLds && matsL2) RT_LAUNCH_K(true, 1024, 1, true, true, false, true, true);
+    else if (useStash && hitLds) RT_LAUNCH_K(true, 1024, 1, true, true, false, true);
+    else if (useStash) RT_LAUNCH_K(true, 1024, 1, true, false, false, true);
     else if (tree) RT_LAUNCH_T(false, 2);
     else if (flat) RT_LAUNCH_T(true, 1);
     else if (ldsTables) RT_LAUNCH_T(true, 0);
@@ -954,6 +967,7 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
 #undef RT_LAUNCH_T
 #undef RT_LAUNCH
 #undef RT_LAUNCH_K
+#undef RT_LAUNCH_FN
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
@@ -1252,6 +1266,13 @@ void rt_destroy(rt_ctx* ctx) {
     ctx->gridCells.Release();
     ctx->sgEntries.Release();
     ctx->sgGlobal.Release();
+    ctx->sgSph.Release();
+    for (auto& x : ctx->extraIdx) {
+        x.cells.Release();
+        x.entries.Release();
+        x.global.Release();
+    }
+    ctx->lightRecs.Release();
     ctx->radius.Release();
     ctx->mats.Release();
     ctx->hdr.Release();
@@ -1303,9 +1324,13 @@ int rt_set_workspace_limit(rt_ctx* ctx, uint64_t bytes) {
 }
 
 int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* materials, uint32_t n, const rt_camera* camera,
-                    const rt_light* sun, const rt_material* sky, float exposure_scale) {
-    if (!ctx || !spheres || !materials || !camera || !sun || !sky || n == 0)
+                    const rt_light* lights, uint32_t n_lights, const rt_material* sky, float exposure_scale) {
+    if (!ctx || !spheres || !materials || !camera || (!lights && n_lights != 0) || !sky || n == 0)
         return Fail(RT_ERR_INVALID_ARG, "rt_scene_upload: null pointer or empty scene");
+    if (n_lights > RT_MAX_LIGHTS) return Fail(RT_ERR_INVALID_ARG, "rt_scene_upload: more than RT_MAX_LIGHTS lights");
+    // light 0 keeps the single-light kernel path's slots; an empty list is uploaded as one dark light that is never consulted
+    const rt_light noLight{{0.f, 1.f, 0.f}, {0.f, 0.f, 0.f}, 0.f};
+    const rt_light* sun = n_lights ? lights : &noLight;
     RT_HIP(hipSetDevice(ctx->device));
     int rc;
     if ((rc = BatchFlush(ctx)) != RT_OK) return rc;  // pending frames were asked of the scene that is being replaced
@@ -1346,7 +1371,41 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     }
 
     ShadowGrid SG;
-    if (ctx->useShadowGrid) BuildShadowGrid(spheres, L, sun->direction, (L.gridOn || L.nLevels > 1) ? EnvU32("RT_SHADOW_CELLS", 256u) : 64u, SG);
+    if (ctx->useShadowGrid && n_lights != 0) BuildShadowGrid(spheres, L, sun->direction, (L.gridOn || L.nLevels > 1) ? EnvU32("RT_SHADOW_CELLS", 256u) : 64u, SG);
+    // lights 1 .. : one index each, in global memory (256 x 256 cells at most), and their records
+    std::vector<rtd::LightRec> recs;
+    for (uint32_t k = 1; k < n_lights; ++k) {
+        ShadowGrid G2;
+        if (ctx->useShadowGrid) BuildShadowGrid(spheres, L, lights[k].direction, EnvU32("RT_SHADOW_CELLS", 256u), G2);
+        rt_ctx::ExtraLight& X = ctx->extraIdx[k];
+        rtd::LightRec R{};
+        for (int c = 0; c < 3; ++c) {
+            R.sun_dir[c] = lights[k].direction[c];
+            R.sun_rad[c] = lights[k].luminance * lights[k].color[c];  // m_luminance * m_color, light.cpp:27
+            R.cam_o[c] = camera->origin[c];
+        }
+        R.sg_enabled = G2.enabled ? 1u : 0u;
+        if (G2.enabled) {
+            if ((rc = X.cells.Reserve(G2.cellStart.size())) != RT_OK) return rc;
+            if ((rc = X.entries.Reserve(G2.entries.size() + 1)) != RT_OK) return rc;
+            if ((rc = X.global.Reserve(G2.global.size() + 1)) != RT_OK) return rc;
+            RT_HIP(hipMemcpy(X.cells.ptr, G2.cellStart.data(), G2.cellStart.size() * 2, hipMemcpyHostToDevice));
+            if (!G2.entries.empty()) RT_HIP(hipMemcpy(X.entries.ptr, G2.entries.data(), G2.entries.size() * 2, hipMemcpyHostToDevice));
+            if (!G2.global.empty()) RT_HIP(hipMemcpy(X.global.ptr, G2.global.data(), G2.global.size() * 2, hipMemcpyHostToDevice));
+            for (int c = 0; c < 3; ++c) {
+                R.sg_e1[c] = G2.e1[c];
+                R.sg_e2[c] = G2.e2[c];
+            }
+            R.sg_u0 = G2.u0; R.sg_v0 = G2.v0; R.sg_inv_cell = G2.invCell; R.sg_p0sq = G2.p0sq;
+            R.sg_nx = G2.nx; R.sg_ny = G2.ny; R.sg_nglobal = (uint32_t)G2.global.size();
+            R.cell_start = X.cells.ptr; R.entries = X.entries.ptr; R.global = X.global.ptr;
+        }
+        recs.push_back(R);
+    }
+    if (!recs.empty()) {
+        if ((rc = ctx->lightRecs.Reserve(recs.size())) != RT_OK) return rc;
+        RT_HIP(hipMemcpy(ctx->lightRecs.ptr, recs.data(), recs.size() * sizeof(rtd::LightRec), hipMemcpyHostToDevice));
+    }
     if (SG.enabled) {
         if ((rc = ctx->sgCells.Reserve(SG.cellStart.size())) != RT_OK) return rc;
         if ((rc = ctx->sgEntries.Reserve(SG.entries.size() + 1)) != RT_OK) return rc;
@@ -1354,6 +1413,12 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
         RT_HIP(hipMemcpy(ctx->sgCells.ptr, SG.cellStart.data(), SG.cellStart.size() * 2, hipMemcpyHostToDevice));
         if (!SG.entries.empty()) RT_HIP(hipMemcpy(ctx->sgEntries.ptr, SG.entries.data(), SG.entries.size() * 2, hipMemcpyHostToDevice));
         if (!SG.global.empty()) RT_HIP(hipMemcpy(ctx->sgGlobal.ptr, SG.global.data(), SG.global.size() * 2, hipMemcpyHostToDevice));
+        if (L.gridOn || L.nLevels > 1) {  // the index stays in global memory: spheres side by side with the ids
+            std::vector<float4> sph(SG.entries.size() + 1, make_float4(0.f, 0.f, 0.f, -1e30f));
+            for (size_t k = 0; k < SG.entries.size(); ++k) sph[k] = L.scan[SG.entries[k]];
+            if ((rc = ctx->sgSph.Reserve(sph.size())) != RT_OK) return rc;
+            RT_HIP(hipMemcpy(ctx->sgSph.ptr, sph.data(), sph.size() * sizeof(float4), hipMemcpyHostToDevice));
+        }
     }
 
     if (L.gridOn) {
@@ -1375,11 +1440,14 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
         b.grid_rmax_over_h = L.gridRmaxOverH;
         b.grid_big_norm = L.gridBigNorm;
     }
+    b.n_lights = n_lights;
+    b.extra_lights = recs.empty() ? nullptr : ctx->lightRecs.ptr;
     b.sg_enabled = SG.enabled ? 1u : 0u;
     if (SG.enabled) {
         b.sg_cell_start = ctx->sgCells.ptr;
         b.sg_entries = ctx->sgEntries.ptr;
         b.sg_global = ctx->sgGlobal.ptr;
+        b.sg_sph = (L.gridOn || L.nLevels > 1) ? ctx->sgSph.ptr : nullptr;
         b.sg_nx = SG.nx;
         b.sg_ny = SG.ny;
         b.sg_nglobal = (uint32_t)SG.global.size();

@@ -296,9 +296,11 @@ RT_DEV bool claim_block(const TraceParams& p, SceneConsts* ldsK, uint32_t lane, 
 // 64 fresh paths straight into registers, scan, and the lanes that missed pop stashed hits until the wave is full of
 // hits.  Scans run with ~59 live rays, hit processing with ~58 lanes instead of 36.  Every path sees the same sequence of
 // operations on the same values as before: only WHEN a hit is processed changes, never what is computed.
-template <bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds = false, bool kCarry = false, bool kStash = false, bool kMatsL2 = false,
-          bool kSgLds = false>
-__global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams p) {
+// kLights (trace_body only): false = ONE light, the reference's scene (rt_trace_kernel); true = the scene's LIST of lights
+// (rt_trace_kernel_lights: Material::Shade's loop, material.cpp:4-13).  Two entry kernels over one body, so that the single-light
+// kernels' code and register allocation are exactly what they were without the list.
+template <bool kLights, bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds, bool kCarry, bool kStash, bool kMatsL2, bool kSgLds>
+__device__ __forceinline__ void trace_body(const TraceParams& p) {
     static_assert(!kSgLds || (kScan == 3 && !kLds && kHitLds), "shadow index in LDS next to the grid's cells: the global-tables grid variant");
     static_assert(!kMatsL2 || (kHitLds && kStash && kLds), "materials through L2: a flavour of the all-in-LDS stash variants");
     constexpr bool kMfma = kScan == 1 || kScan == 2;  // matrix-core filter; kScan == 3: cell-grid scan (rt_scan.h scan_list_grid)
@@ -491,9 +493,50 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         const bool scattered = scatter_only(m, rd, nrm, draws, atten, nextDir, tex, mt, K.sampler);  // Scatter first: it draws (spheres-app.cpp:246)
         RT_STAMP(th1);
         const bool cont = (depth < p.max_depth) && scattered;  // spheres-app.cpp:247
+        if (kLights) {
+            // Material::Shade over the scene's LIST of lights (material.cpp:4-13): directLighting = 0, += light->Shade(...) in list
+            // order; every light casts its shadow ray (one traversal each), answered by the light's own footprint index -- or, for
+            // a hit point outside it, by the any-hit over every entry.  (One light -- the reference's scene -- takes the path below.)
+            RT_SITE(H_MULTI);
+            V3 emitOnly;
+            shade_value(K, m, tex, pos, nrm, false, emitOnly, localOcc, mt);  // Emit + 0
+            V3 direct = v3(0.f, 0.f, 0.f);
+            const float pp = dot3(pos, pos);
+            for (uint32_t k = 0; k < p.n_lights; ++k) {
+                bool occ;
+                V3 sh;
+                if (k == 0u) {
+                    occ = (K.sg_enabled && pp <= K.sg_p0sq)
+                              ? shadow_query(K, scanTab, sgCell, sgEntries, sgGlobal, p.sg_glob16 != 0u, globSph, globIds, (!kLds && kScan >= 2) ? p.sg_sph : nullptr, pos, sunDir, aSun)
+                              : any_hit_all(scanTab, p.n_padded, pos, sunDir, aSun);
+                    sh = occ ? v3(0.f, 0.f, 0.f) : shade_only(K, m, tex, pos, nrm, mt);
+                } else {
+                    const LightRec& Lk = p.extra_lights[k - 1u];
+                    const V3 dirK = v3(Lk.sun_dir[0], Lk.sun_dir[1], Lk.sun_dir[2]);
+                    const float aK = dot3(dirK, dirK);
+                    occ = (Lk.sg_enabled && pp <= Lk.sg_p0sq)
+                              ? shadow_query(Lk, scanTab, Lk.cell_start, Lk.entries, Lk.global, false, globSph, globIds, (const float4*)nullptr, pos, dirK, aK)
+                              : any_hit_all(scanTab, p.n_padded, pos, dirK, aK);
+                    sh = occ ? v3(0.f, 0.f, 0.f) : shade_only(Lk, m, tex, pos, nrm, mt);
+                }
+                ++nTrav;
+                ++pathTrav;
+                direct = direct + sh;  // (an occluded light's Shade is XM_Zero, light.cpp:15-18)
+            }
+            rad = rad + thr * (emitOnly + direct);  // radiance += throughput * (Emit + Shade)
+            if (cont) {
+                thr = thr * atten;
+                ro = pos;
+                rd = nextDir;
+                ++depth;
+            } else {
+                finished = true;
+            }
+            return;
+        }
         const bool useIndex = K.sg_enabled && dot3(pos, pos) <= K.sg_p0sq;
         bool occluded = false;
-        if (useIndex) occluded = shadow_query(K, scanTab, sgCell, sgEntries, sgGlobal, p.sg_glob16 != 0u, globSph, globIds, pos, sunDir, aSun);
+        if (useIndex) occluded = shadow_query(K, scanTab, sgCell, sgEntries, sgGlobal, p.sg_glob16 != 0u, globSph, globIds, (!kLds && kScan >= 2) ? p.sg_sph : nullptr, pos, sunDir, aSun);
         RT_STAMP(th2);
         // the Blinn-Phong value (two normalisations, two pows) is only needed when the sun is visible or unknown
         shade_value(K, m, tex, pos, nrm, !occluded, local, localOcc, mt);
@@ -914,6 +957,18 @@ __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams
         atomicAdd(&g_dbg[17], cyHit[5]);
 #endif
     }
+}
+
+template <bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds = false, bool kCarry = false, bool kStash = false, bool kMatsL2 = false,
+          bool kSgLds = false>
+__global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams p) {
+    trace_body<false, kLds, kThreads, kScan, kCache, kHitLds, kCarry, kStash, kMatsL2, kSgLds>(p);
+}
+// ... and for scenes whose light list has another length than one (rt_scene_upload, n_lights != 1)
+template <bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds = false, bool kCarry = false, bool kStash = false, bool kMatsL2 = false,
+          bool kSgLds = false>
+__global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel_lights(const TraceParams p) {
+    trace_body<true, kLds, kThreads, kScan, kCache, kHitLds, kCarry, kStash, kMatsL2, kSgLds>(p);
 }
 
 // ============================================================ ray-generation tables (A1, A9)

@@ -107,6 +107,16 @@ constexpr uint32_t kMaxFramesInFlight = 16;  // regions of the sample ring
 // chasing id -> sphere through the tables (two dependent L2 reads per pair of entries in the large-scene variants).
 RT_DEV uint32_t sg_glob_slots(uint32_t nGlobal) { return nGlobal ? nGlobal + (nGlobal * 2u + 15u) / 16u : 0u; }
 
+// Lights 1 .. n_lights-1 of the scene's list (light 0 lives in TraceParams / SceneConsts as before): direction, radiance and
+// the light's own shadow index, in global memory.  Member names equal SceneConsts' so that shade_value / shadow_query take either.
+struct LightRec {
+    float sun_dir[3], sun_rad[3];
+    float cam_o[3];
+    float sg_e1[3], sg_e2[3], sg_u0, sg_v0, sg_inv_cell, sg_p0sq;
+    uint32_t sg_nx, sg_ny, sg_nglobal, sg_enabled;
+    const uint16_t *cell_start, *entries, *global;
+};
+
 struct TraceParams {
     // scene
     // Spheres are stored CLUSTERED: groups of four spatially close spheres (Morton order; large spheres alone),
@@ -143,12 +153,16 @@ struct TraceParams {
     const uint16_t* sg_cell_start;  // [sg_nx * sg_ny + 1]
     const uint16_t* sg_entries;     // clustered entry indices per cell
     const uint16_t* sg_global;      // entries tested for every query (footprints covering much of the grid)
+    const float4* sg_sph;           // large scenes (index in global memory): the scan record of every sg_entries element, so that a walk
+                                    // requests ids and spheres together instead of id -> sphere (two dependent L2 reads); else null
     uint32_t sg_nx, sg_ny, sg_nglobal, sg_nentries, sg_enabled, sg_in_lds;
     uint32_t sg_glob16;             // float4 slots of the global list's LDS copy (spheres, then ids) in front of the tables; 0: none (unit kernels)
     float sg_e1[3], sg_e2[3], sg_u0, sg_v0, sg_inv_cell, sg_p0sq;
     float cam_o[3], cam_x[3], cam_y[3], cam_oip[3];
     float aperture, focal;
-    float sun_dir[3], sun_rad[3];  // sun_rad = luminance * colour (light.cpp:27, left factor)
+    float sun_dir[3], sun_rad[3];  // light 0: sun_rad = luminance * colour (light.cpp:27, left factor)
+    uint32_t n_lights;             // lights in the scene's list (spheres-app.h:38); 1 = the reference's scene
+    const LightRec* extra_lights;  // [n_lights - 1] lights 1 .. (global memory)
     float sky_emit[3];             // luminance * colour (material.cpp:172-175)
     float exposure;
     // work

@@ -135,6 +135,33 @@ RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V
     return scattered;
 }
 
+// DirectionalLight::Shade's unoccluded value for the light described by p (light.cpp:21-40; viewOrigin is always the camera
+// origin, spheres-app.cpp:250).
+template <class P>
+RT_DEV V3 shade_only(const P& p, const Mat& m, V3 tex, V3 pos, V3 nrm, const MathTabs& mt = default_math_tabs()) {
+    RT_SITE(H_SHADE);
+    // Material getters (material.h:26-29,42-45,59-62,76-79)
+    V3 albedo = v3(0.f, 0.f, 0.f), f0 = v3(0.04f, 0.04f, 0.04f);
+    if (m.type == RT_MAT_DIELECTRIC_OPAQUE) albedo = tex;
+    else if (m.type == RT_MAT_METAL) f0 = tex;
+    else if (m.type == RT_MAT_EMISSIVE) f0 = v3(0.f, 0.f, 0.f);
+    const float smooth = (m.type == RT_MAT_EMISSIVE) ? 0.f : m.smoothness;
+
+    const V3 L = v3(p.sun_dir[0], p.sun_dir[1], p.sun_dir[2]);
+    const float nDotL = sat1(dot3(nrm, L));
+    const V3 radianceIn = v3(p.sun_rad[0] * nDotL, p.sun_rad[1] * nDotL, p.sun_rad[2] * nDotL);
+    const V3 viewDir = normalize3(v3(p.cam_o[0], p.cam_o[1], p.cam_o[2]) - pos);
+    const V3 halfVector = normalize3(L + viewDir);
+    const float nDotH = sat1(dot3(nrm, halfVector));
+    const float nDotV2 = sat1(dot3(viewDir, nrm));
+    const float p5 = rt_powf(1.f - nDotV2, 5.f);
+    const float ps = rt_powf(nDotH, smooth, mt);
+    const V3 one = v3(1.f, 1.f, 1.f);
+    const V3 reflectance = f0 + (one - f0) * p5;
+    const V3 spec = ((reflectance * 0.125f) * (smooth + 8.f)) * ps;
+    return radianceIn * (albedo + spec);
+}
+
 // Emit + DirectionalLight::Shade's unoccluded value (light.cpp:21-40) and Emit + 0 (its value when occluded).
 template <class P>
 RT_DEV void shade_value(const P& p, const Mat& m, V3 tex, V3 pos, V3 nrm, bool wantShade, V3& local, V3& localOccluded,
@@ -144,31 +171,7 @@ RT_DEV void shade_value(const P& p, const Mat& m, V3 tex, V3 pos, V3 nrm, bool w
     if (m.type == RT_MAT_EMISSIVE) emit = m.luminance * tex;  // material.cpp:172-175; 0 for every other material
     localOccluded = emit + v3(0.f, 0.f, 0.f);  // Shade returns XM_Zero when the sun is occluded (light.cpp:15-18)
     local = localOccluded;
-    if (wantShade) {
-        RT_SITE(H_SHADE);
-        // Material getters (material.h:26-29,42-45,59-62,76-79)
-        V3 albedo = v3(0.f, 0.f, 0.f), f0 = v3(0.04f, 0.04f, 0.04f);
-        if (m.type == RT_MAT_DIELECTRIC_OPAQUE) albedo = tex;
-        else if (m.type == RT_MAT_METAL) f0 = tex;
-        else if (m.type == RT_MAT_EMISSIVE) f0 = v3(0.f, 0.f, 0.f);
-        const float smooth = (m.type == RT_MAT_EMISSIVE) ? 0.f : m.smoothness;
-
-        // DirectionalLight::Shade, light.cpp:21-40 (viewOrigin is always the camera origin, spheres-app.cpp:250)
-        const V3 L = v3(p.sun_dir[0], p.sun_dir[1], p.sun_dir[2]);
-        const float nDotL = sat1(dot3(nrm, L));
-        const V3 radianceIn = v3(p.sun_rad[0] * nDotL, p.sun_rad[1] * nDotL, p.sun_rad[2] * nDotL);
-        const V3 viewDir = normalize3(v3(p.cam_o[0], p.cam_o[1], p.cam_o[2]) - pos);
-        const V3 halfVector = normalize3(L + viewDir);
-        const float nDotH = sat1(dot3(nrm, halfVector));
-        const float nDotV2 = sat1(dot3(viewDir, nrm));
-        const float p5 = rt_powf(1.f - nDotV2, 5.f);
-        const float ps = rt_powf(nDotH, smooth, mt);
-        const V3 one = v3(1.f, 1.f, 1.f);
-        const V3 reflectance = f0 + (one - f0) * p5;
-        const V3 spec = ((reflectance * 0.125f) * (smooth + 8.f)) * ps;
-        const V3 shade = radianceIn * (albedo + spec);
-        local = emit + shade;
-    }
+    if (wantShade) local = emit + shade_only(p, m, tex, pos, nrm, mt);
 }
 
 // Scatter, then Emit + Shade with the sun assumed visible (the scan-based shadow path decides later).
@@ -227,7 +230,7 @@ RT_DEV bool sphere_any_hit(const float4 S, V3 o, V3 d, float a, float ya, bool a
 template <class P>
 RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint16_t* __restrict__ cellStart,
                          const uint16_t* __restrict__ entries, const uint16_t* __restrict__ glob, bool globInLds,
-                         const float4* globSph, const uint16_t* globIds, V3 pos, V3 L, float aL) {
+                         const float4* globSph, const uint16_t* globIds, const float4* __restrict__ entrySph, V3 pos, V3 L, float aL) {
     RT_SITE(H_SHADOWQ);
     bool occluded = false;
     unsigned long long queue = 0ull;
@@ -260,20 +263,21 @@ RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint1
     };
     // two entries per round: both ids, then both spheres, are requested together -- one entry at a time costs two LDS round
     // trips back to back (id, then sphere) per entry with nothing to do in between
-    auto walk = [&](const uint16_t* __restrict__ list, uint32_t first, uint32_t end) __attribute__((always_inline)) {
+    // sph: the spheres of the list's elements side by side with the ids (large scenes: rt_params.h sg_sph), or null: tab[id]
+    auto walk = [&](const uint16_t* __restrict__ list, const float4* __restrict__ sph, uint32_t first, uint32_t end) __attribute__((always_inline)) {
         RT_SITE(H_SQ_WALK);
         uint32_t e = first;
         for (; e + 2u <= end; e += 2u) {
             RT_SITE(H_SQ_ROUND);
             const uint32_t idA = list[e], idB = list[e + 1u];
-            const float4 SA = tab[idA], SB = tab[idB];
+            const float4 SA = sph ? sph[e] : tab[idA], SB = sph ? sph[e + 1u] : tab[idB];
             consider(idA, SA);
             consider(idB, SB);
         }
         if (e < end) {
             RT_SITE(H_SQ_TAIL1);
             const uint32_t idA = list[e];
-            consider(idA, tab[idA]);
+            consider(idA, sph ? sph[e] : tab[idA]);
         }
     };
     if (globInLds) {
@@ -291,7 +295,7 @@ RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint1
             consider(globIds[k], globSph[k]);
         }
     } else {
-        walk(glob, 0u, p.sg_nglobal);
+        walk(glob, nullptr, 0u, p.sg_nglobal);
     }
     const float u = dot3(pos, v3(p.sg_e1[0], p.sg_e1[1], p.sg_e1[2]));
     const float v = dot3(pos, v3(p.sg_e2[0], p.sg_e2[1], p.sg_e2[2]));
@@ -299,7 +303,7 @@ RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint1
     if (fx >= 0.f && fy >= 0.f && fx < (float)p.sg_nx && fy < (float)p.sg_ny) {
         RT_SITE(H_SQ_CELL);
         const uint32_t c = (uint32_t)fy * p.sg_nx + (uint32_t)fx;
-        walk(entries, (uint32_t)cellStart[c], (uint32_t)cellStart[c + 1]);
+        walk(entries, entrySph, (uint32_t)cellStart[c], (uint32_t)cellStart[c + 1]);
     }
     while (nq > 0u && !occluded) {
         RT_SITE(H_SQ_ROOTS);
@@ -308,6 +312,21 @@ RT_DEV bool shadow_query(const P& p, const float4* __restrict__ tab, const uint1
         --nq;
         occluded = sphere_any_hit(tab[id], pos, L, aL, yaL, aOk);
     }
+    return occluded;
+}
+
+// The any-hit of one shadow ray over EVERY scan entry (the reference's IsOccluded, light.cpp:13-15): the multi-light path's answer
+// for hit points outside a light's index (|p| > P0; rare).  Padding entries (r*r = -1e30) never hit.
+RT_DEV bool any_hit_all(const float4* __restrict__ tab, uint32_t nEntries, V3 pos, V3 L, float aL) {
+#if RT_MARKSTEIN
+    const bool aOk = (unsigned)(float_exponent(aL) + 19) <= 119u;
+    const float yaL = recip_rn(aL);
+#else
+    const bool aOk = false;
+    const float yaL = 0.f;
+#endif
+    bool occluded = false;
+    for (uint32_t e = 0; e < nEntries && !occluded; ++e) occluded = sphere_any_hit(tab[e], pos, L, aL, yaL, aOk);
     return occluded;
 }
 

@@ -10,7 +10,7 @@ namespace rtd {
 #define RT_SITE_LIST(X) \
     X(K_WAVE) X(K_ITER) X(K_PATHLIST) X(K_PARTIAL) X(P_HALTON) X(M_DIV_SLOW) X(K_POP) X(K_POP_LANE) X(K_PUSH) \
     X(K_PUSH_LANE) X(K_PROCESS) X(K_GEN) X(K_GEN_LANE) X(K_NEXTBLOCK) X(K_CLAIM) X(K_TRANS_MISS) X(K_TRANS_HIT) \
-    X(K_TRANS_SHADOW) X(K_FINISH) X(H_PROCESS) X(H_SCATTER) X(H_SHADEV) X(H_TRANSPARENT) X(H_METAL) X(H_OPAQUE) \
+    X(K_TRANS_SHADOW) X(K_FINISH) X(H_PROCESS) X(H_MULTI) X(H_SCATTER) X(H_SHADEV) X(H_TRANSPARENT) X(H_METAL) X(H_OPAQUE) \
     X(H_OPAQUE_DIFFUSE) X(H_SHADOWQ) X(H_SQ_WALK) X(H_SQ_CONSIDER) X(H_SQ_GROUND) X(H_SQ_GTAIL) X(H_SQ_ROUND) X(H_SQ_TAIL1) X(H_SQ_CELL) \
     X(H_SQ_ROOTS) X(H_SQ_FULL) X(H_SHADE) X(H_INDEXED) X(H_FARHIT) X(S_SCAN) X(S_TILEPAIR) X(S_SINGLE) \
     X(S_SINGLE_PUSH0) X(S_SINGLE_PUSH1) X(S_PASS) X(S_TAKE) X(S_PUSH_WORD) X(S_TAKE_PUSH0) X(S_TAKE_PUSH1) X(S_ASTEP) X(S_ASTEP2) X(S_APUSH) X(S_DRAIN) X(S_BSTEP) X(S_BSTEP2) X(S_BMIN) \

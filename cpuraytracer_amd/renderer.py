@@ -61,9 +61,14 @@ class HipRenderer:
         mat = np.ascontiguousarray(scene.materials)
         assert sph.dtype.itemsize == 16 and mat.dtype.itemsize == 48
         cam = _capi.RtCamera.from_buffer_copy(bytes(scene.camera))
-        sun = _capi.RtLight.from_buffer_copy(bytes(scene.sun))
+        # m_lights (spheres-app.h:38): scene.lights when the scene carries a list (it may be empty), else the generators' single sun
+        ls = getattr(scene, "lights", None)
+        ls = [scene.sun] if ls is None else list(ls)
+        lights = (_capi.RtLight * max(1, len(ls)))()
+        for k, l in enumerate(ls):
+            lights[k] = _capi.RtLight.from_buffer_copy(bytes(l))
         sky = _capi.RtMaterial.from_buffer_copy(bytes(scene.sky))
-        check(self._L.rt_scene_upload(self._h, sph.ctypes.data, mat.ctypes.data, sph.shape[0], C.byref(cam), C.byref(sun),
+        check(self._L.rt_scene_upload(self._h, sph.ctypes.data, mat.ctypes.data, sph.shape[0], C.byref(cam), lights, len(ls),
                                       C.byref(sky), float(scene.exposure_scale)))
 
     def render(self, W, H, s0, s1, max_depth, seed, rowset=None, stats=True):

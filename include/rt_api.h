@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RT_API_VERSION 1
+#define RT_API_VERSION 2 /* 2: rt_scene_upload takes the LIST of lights (spheres-app.h:38 m_lights), not one sun */
 
 enum rt_status {
     RT_OK = 0,
@@ -143,8 +143,14 @@ int rt_set_workspace_limit(rt_ctx* ctx, uint64_t bytes);
 /* Limit: the clustered scan table (groups of four, padded) must stay below 65,536 entries
  * — about 65,000 spheres — because work lists, the shadow index and the closest-hit keys
  * carry entry ids in 16 bits; larger scenes are rejected here with RT_ERR_INVALID_ARG. */
+/* lights: SpheresApp::m_lights (spheres-app.h:38, filled at spheres-app.cpp:129) as flat records, in list order -- the order
+ * Material::Shade adds their contributions in (material.cpp:4-13); 0 <= n_lights <= RT_MAX_LIGHTS (lights may be NULL when
+ * n_lights == 0: Shade then returns zero and no shadow ray is cast).  Every light answers its any-hit shadow query through
+ * an exact footprint index of its own; a light below the horizon of a surface contributes nDotL = 0 exactly as in
+ * the reference.  One light (the reference's scene) runs the single-light kernel path unchanged. */
+#define RT_MAX_LIGHTS 8
 int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* materials, uint32_t n,
-                    const rt_camera* camera, const rt_light* sun, const rt_material* sky,
+                    const rt_camera* camera, const rt_light* lights, uint32_t n_lights, const rt_material* sky,
                     float exposure_scale);
 
 /* ----------------------------------------------------------------- render */

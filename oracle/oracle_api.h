@@ -28,7 +28,7 @@ int orc_build_scene(const char* name, uint64_t seed, float aspect, float apertur
                     rt_material* sky, float* exposure_scale);
 
 int orc_scene_upload(orc_ctx* ctx, const rt_sphere* spheres, const rt_material* materials, uint32_t n,
-                     const rt_camera* camera, const rt_light* sun, const rt_material* sky, float exposure_scale);
+                     const rt_camera* camera, const rt_light* lights, uint32_t n_lights, const rt_material* sky, float exposure_scale);
 int orc_render(orc_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1, uint32_t max_depth,
                uint64_t seed, int accel, int threads, rt_stats* out_stats);
 /* N3: drive material draws from the reference's per-material Halton counters (serial renders only) */

@@ -46,13 +46,15 @@ int orc_build_scene(const char* name, uint64_t seed, float aspect, float apertur
 }
 
 int orc_scene_upload(orc_ctx* ctx, const rt_sphere* spheres, const rt_material* materials, uint32_t n, const rt_camera* camera,
-                     const rt_light* sun, const rt_material* sky, float exposure_scale) {
-    if (!ctx || !spheres || !materials || !camera || !sun || !sky || n == 0) return Fail("orc_scene_upload: invalid argument");
+                     const rt_light* lights, uint32_t n_lights, const rt_material* sky, float exposure_scale) {
+    if (!ctx || !spheres || !materials || !camera || (!lights && n_lights != 0) || !sky || n == 0) return Fail("orc_scene_upload: invalid argument");
     FlatScene fs;
     fs.spheres.assign(spheres, spheres + n);
     fs.materials.assign(materials, materials + n);
     fs.camera = *camera;
-    fs.sun = *sun;
+    fs.lightsGiven = true;
+    fs.lights.assign(lights, lights + n_lights);
+    if (n_lights) fs.sun = lights[0];
     fs.sky = *sky;
     fs.exposureScale = exposure_scale;
     ctx->app.LoadScene(fs, 1);

@@ -102,7 +102,7 @@ def lib():
                                       C.POINTER(C.c_uint32), C.POINTER(RtCamera), C.POINTER(RtLight),
                                       C.POINTER(RtMaterial), C.POINTER(C.c_float)]
         L.orc_scene_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(RtCamera),
-                                       C.POINTER(RtLight), C.POINTER(RtMaterial), C.c_float]
+                                       C.POINTER(RtLight), C.c_uint32, C.POINTER(RtMaterial), C.c_float]
         L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, RtRowset, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.c_uint64, C.c_int, C.c_int, C.POINTER(RtStats)]
         L.orc_use_reference_halton_counters.argtypes = [C.c_int]
@@ -176,6 +176,32 @@ def whole_image(H):
     return RtRowset(0, H, H, 0, 1)
 
 
+def light_array(scene):
+    """(ctypes array of rt_light, count): scene.lights (any sequence of rt_light-layout structs, may be empty) when the scene has
+    one, else the generators' single sun."""
+    ls = getattr(scene, "lights", None)
+    ls = [scene.sun] if ls is None else list(ls)
+    arr = (RtLight * max(1, len(ls)))()
+    for k, l in enumerate(ls):
+        arr[k] = RtLight.from_buffer_copy(bytes(l))
+    return arr, len(ls)
+
+
+def make_light(direction, color=(1.0, 0.97, 0.88), luminance=40000.0):
+    """DirectionalLight(dir, XMCOLOR(color), luminance) as the flat rt_light record (light.cpp:4-9): direction normalised in
+    binary32 (XMVector3Normalize), colour through the 8-bit XMCOLOR quantisation (XMLoadColor)."""
+    d = np.asarray(direction, dtype=np.float32)
+    n = np.float32(np.sqrt(np.float32(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])))
+    d = (d / n).astype(np.float32)
+    l = RtLight()
+    for k in range(3):
+        l.direction[k] = float(d[k])
+        byte = int(np.rint(np.float32(min(max(float(color[k]), 0.0), 1.0)) * np.float32(255.0)))
+        l.color[k] = float(np.float32(byte) * np.float32(1.0 / 255.0))
+    l.luminance = float(luminance)
+    return l
+
+
 class Oracle:
     def __init__(self):
         self._h = C.c_void_p()
@@ -199,9 +225,9 @@ class Oracle:
         mat = np.ascontiguousarray(scene.materials)
         assert sph.dtype.itemsize == 16 and mat.dtype.itemsize == 48
         cam = RtCamera.from_buffer_copy(bytes(scene.camera))
-        sun = RtLight.from_buffer_copy(bytes(scene.sun))
+        lights, n_lights = light_array(scene)  # m_lights (spheres-app.h:38): scene.lights when the scene has one, else [scene.sun]
         sky = RtMaterial.from_buffer_copy(bytes(scene.sky))
-        _check(lib().orc_scene_upload(self._h, sph.ctypes.data, mat.ctypes.data, sph.shape[0], C.byref(cam), C.byref(sun),
+        _check(lib().orc_scene_upload(self._h, sph.ctypes.data, mat.ctypes.data, sph.shape[0], C.byref(cam), lights, n_lights,
                                       C.byref(sky), float(scene.exposure_scale)))
 
     def render(self, W, H, s0, s1, max_depth, seed, rowset=None, accel=ACCEL_LIST, threads=1):

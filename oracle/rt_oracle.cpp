@@ -683,7 +683,14 @@ void SpheresApp::LoadScene(const FlatScene& flat, uint64_t bvhAxisSeed) {
         RecordRay(ray, 1.f, occluded ? 1.f : 0.f);
         return occluded;
     };
-    m_lights.push_back(std::make_unique<DirectionalLight>(flat.sun, lightOcclusionTest));
+    // (every light of the list gets the same occlusion test, as spheres-app.cpp:124-129 builds it; Material::Shade adds their
+    // contributions in list order, material.cpp:4-13)
+    m_lights.clear();
+    if (flat.lightsGiven) {
+        for (const rt_light& l : flat.lights) m_lights.push_back(std::make_unique<DirectionalLight>(l, lightOcclusionTest));
+    } else {
+        m_lights.push_back(std::make_unique<DirectionalLight>(flat.sun, lightOcclusionTest));
+    }
     m_activeAccel = m_sceneList.get();
     Clear();
 }

@@ -291,7 +291,9 @@ struct FlatScene {
     std::vector<rt_sphere> spheres;
     std::vector<rt_material> materials;
     rt_camera camera{};
-    rt_light sun{};
+    rt_light sun{};                // the scene generators' single light (spheres-app.cpp:129) ...
+    std::vector<rt_light> lights;  // ... and the list the app is loaded with (spheres-app.h:38 m_lights); empty: {sun}
+    bool lightsGiven = false;      // true: `lights` is the list, even when it is empty (Material::Shade then returns XM_Zero)
     rt_material sky{};
     float exposureScale = 0.f;
 };

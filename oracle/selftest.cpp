@@ -21,7 +21,7 @@ int main() {
         if (orc_build_scene(name, 1, 1.5f, -1.f, cap, sp.data(), mt.data(), &n, &cam, &sun, &sky, &exposure) != 0) return 2;
         orc_ctx* ctx = nullptr;
         if (orc_create(&ctx) != 0) return 2;
-        if (orc_scene_upload(ctx, sp.data(), mt.data(), n, &cam, &sun, &sky, exposure) != 0) return 2;
+        if (orc_scene_upload(ctx, sp.data(), mt.data(), n, &cam, &sun, 1u, &sky, exposure) != 0) return 2;
         const uint32_t W = 48, H = 30;
         const rt_rowset whole{0, H, H, 0, 1};
         rt_stats a{}, b{};

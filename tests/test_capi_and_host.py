@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(built):
     assert len(declared) >= 20
     for name in declared:
         assert hasattr(L, name), "librt_hip.so does not export %s" % name
-    assert L.rt_api_version() == 1
+    assert L.rt_api_version() == 2  # 2: rt_scene_upload takes the light LIST
 
 
 def test_library_contains_gfx950_code_object(built):
@@ -64,7 +64,7 @@ def test_null_arguments_are_rejected_without_touching_the_gpu(built):
     L = _capi.load()
     assert L.rt_render(None, 8, 8, _capi.whole_image(8), 1, 2, 8, 1, None) == 2
     assert b"null ctx" in L.rt_last_error()
-    assert L.rt_scene_upload(None, None, None, 0, None, None, None, 1.0) == 2
+    assert L.rt_scene_upload(None, None, None, 0, None, None, 0, None, 1.0) == 2
     assert L.rt_resolve(None, 1) == 2 and L.rt_download(None, None, None) == 2
 
 

@@ -821,6 +821,73 @@ def test_readers_render_a_pending_batch_that_starts_a_new_picture(hip, scenes_mo
         one.close()
 
 
+# ------------------------------------------------------------------ the scene's LIST of lights (material.cpp:4-13)
+def _far_camera(oracle, aspect):
+    """A camera high above the scene looking at the horizon: most floor hits lie hundreds of units out, beyond every footprint
+    index's radius P0, so the shadow rays of those hits take the any-hit over every entry (any_hit_all)."""
+    cam = oracle.RtCamera()
+    o = (C.c_float * 3)(0.0, 40.0, -60.0)
+    l = (C.c_float * 3)(0.0, 0.0, 400.0)
+    oracle.lib().orc_camera_make(o, l, 35.0, aspect, 10.0, 0.0, C.byref(cam))
+    return cam
+
+
+@pytest.mark.parametrize("name,W,H,spp,n_lights,far", [("cover", 160, 100, 4, 2, False), ("cover", 144, 96, 3, 3, False), ("cover", 96, 64, 3, 0, False),
+                                                       ("cover", 128, 80, 2, 3, True), ("grid10k", 112, 112, 2, 2, False), ("three", 100, 50, 4, 8, False)])
+def test_light_list_images_equal_the_oracle(hip, oracle, scenes_mod, name, W, H, spp, n_lights, far):
+    """rt_scene_upload with the reference's m_lights as a LIST (spheres-app.h:38; Material::Shade adds the lights in list order,
+    material.cpp:4-13): two, three and eight directional lights -- one of them below the horizon (nDotL = 0, and its shadow rays
+    run into the floor), one nearly parallel to the first -- and the empty list.  HDR, LDR and the traversal counters (one shadow
+    ray per light and hit) equal the oracle's, for the flat, the cell-grid and the tiny-scene kernels, and for hit points far
+    outside the footprint indices."""
+    sc = scenes_mod.build_scene(name, 1, W, H)
+    pool = [sc.sun,
+            oracle.make_light((-0.6, 0.7, 0.35), (0.35, 0.55, 1.0), 25000.0),
+            oracle.make_light((0.3, -1.0, 0.2), (1.0, 0.2, 0.2), 30000.0),     # below the horizon of the floor
+            oracle.make_light((1.0, 1.02, 0.99), (0.2, 1.0, 0.3), 9000.0),     # nearly the first light's direction
+            oracle.make_light((0.0, 1.0, 0.0), (1.0, 1.0, 1.0), 5000.0),
+            oracle.make_light((-1.0, 0.25, -1.0), (0.9, 0.8, 0.1), 12000.0),
+            oracle.make_light((0.2, 0.4, -1.0), (0.5, 0.5, 0.9), 7000.0),
+            oracle.make_light((-0.1, 0.9, 0.6), (0.3, 0.3, 0.3), 20000.0)]
+    sc.lights = pool[:n_lights]
+    if far:
+        sc.camera = _far_camera(oracle, W / float(H))
+    hip.upload(sc)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    sg = hip.render(W, H, 1, 1 + spp, 50, 3)
+    hip.resolve()
+    hg, lg = hip.download()
+    so = orc.render(W, H, 1, 1 + spp, 50, 3, threads=8)
+    orc.resolve()
+    ho, lo = orc.download()
+    assert_same(hg, ho, "%s with %d lights: HDR" % (name, n_lights))
+    assert_same(lg, lo, "%s with %d lights: LDR" % (name, n_lights))
+    assert (sg.traversals, sg.segments) == (so.traversals, so.segments)
+    if n_lights >= 2 and not far:
+        # the list matters: the same scene under the first light alone is another picture
+        sc.lights = pool[:1]
+        hip.upload(sc)
+        hip.render(W, H, 1, 1 + spp, 50, 3)
+        assert not np.array_equal(hip.download(ldr=False)[0], hg)
+    del sc.lights
+
+
+def test_one_light_as_a_list_is_the_single_light_scene(hip, scenes_mod):
+    """n_lights == 1 runs the single-light kernels: a scene with lights = [sun] and the scene without the attribute give the same
+    bits (and the committed full-size digests keep pinning that path)."""
+    sc = scenes_mod.build_scene("cover", 1, 192, 128)
+    hip.upload(sc)
+    s0 = hip.render(192, 128, 1, 5, 50, 1)
+    h0 = hip.download(ldr=False)[0]
+    sc.lights = [sc.sun]
+    hip.upload(sc)
+    s1 = hip.render(192, 128, 1, 5, 50, 1)
+    assert_same(hip.download(ldr=False)[0], h0, "lights = [sun]")
+    assert s0.traversals == s1.traversals and s0.segments == s1.segments
+    del sc.lights
+
+
 def test_pipelining_falls_back_where_the_variant_does_not_apply(hip, scenes_mod):
     """grid10k runs the hierarchy scan, which has no carrying variant: the same calls run unpipelined and stay exact."""
     sc = scenes_mod.build_scene("grid10k", 1, 96, 96)

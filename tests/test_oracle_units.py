@@ -468,6 +468,35 @@ def test_known_paths_where_the_reference_bvh_is_not_the_list(oracle):
         assert (tb != tl).all()  # every one of them differs under the reference's accelerator
 
 
+def test_light_list_order_and_dark_lights(oracle):
+    """Material::Shade adds the lights of m_lights in list order (material.cpp:4-13) and every light casts its shadow ray
+    (light.cpp:13): (a) a second light of zero luminance leaves every pixel as it is (x + 0 = x) but doubles the shadow rays;
+    (b) the empty list renders Emit only and casts none; (c) two lights give another picture than either alone."""
+    sc = oracle.build_scene("cover", 1, 1.5)
+    orc = oracle.Oracle()
+    W, H = 96, 64
+    orc.upload(sc)
+    s1 = orc.render(W, H, 1, 3, 50, 1, threads=4)
+    h1, _ = orc.download()
+    dark = oracle.make_light((-0.3, 0.8, 0.5), (1.0, 1.0, 1.0), 0.0)
+    sc.lights = [sc.sun, dark]
+    orc.upload(sc)
+    s2 = orc.render(W, H, 1, 3, 50, 1, threads=4)
+    h2, _ = orc.download()
+    assert np.array_equal(h1.view(np.uint32), h2.view(np.uint32))
+    assert s2.segments == s1.segments and s2.traversals - s2.segments == 2 * (s1.traversals - s1.segments)
+    sc.lights = []
+    orc.upload(sc)
+    s0 = orc.render(W, H, 1, 3, 50, 1, threads=4)
+    h0, _ = orc.download()
+    assert s0.traversals == s0.segments and (h0 <= h1).all() and not np.array_equal(h0, h1)
+    sc.lights = [sc.sun, oracle.make_light((-0.6, 0.7, 0.35), (0.35, 0.55, 1.0), 25000.0)]
+    orc.upload(sc)
+    orc.render(W, H, 1, 3, 50, 1, threads=4)
+    h3, _ = orc.download()
+    assert (h3 >= h1).all() and not np.array_equal(h3, h1)
+
+
 def test_c1_matches_committed_golden(oracle):
     g = np.load(os.path.join(GOLDEN, "c1_three_200x100_spp1_d8.npz"))
     sc = oracle.build_scene("three", 1, 2.0)
