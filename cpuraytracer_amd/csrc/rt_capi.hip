@@ -101,6 +101,7 @@ struct rt_ctx {
     ExtraLight extraIdx[RT_MAX_LIGHTS];
     DevBuf<rtd::LightRec> lightRecs;
     DevBuf<uint16_t> gridCells;  // cell-grid scan: first scan entry per cell
+    DevBuf<uint32_t> gridQ;      // ... and the quantised one-sphere bounds per scan entry (rt_scan.h GridQuant)
     bool useShadowGrid = true;  // RT_SHADOW_GRID=0 keeps every shadow ray on the scan
     DevBuf<float> radius;
     DevBuf<rt_material> mats;
@@ -194,6 +195,8 @@ struct SceneLayout {
     std::vector<uint16_t> gridCellStart;  // [nu * nv + 1]
     uint32_t gridNu = 0, gridNv = 0, gridAxU = 0, gridAxV = 2;
     float gridG0u = 0.f, gridG0v = 0.f, gridInvH = 0.f, gridRmaxOverH = 0.f, gridBigNorm = 0.f;
+    std::vector<uint32_t> gridQ;  // quantised one-sphere bounds per scan entry (rt_scan.h GridQuant), empty: none
+    float gridQc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // Conservative bounding sphere of a set of spheres, in the filter's (C, |C|^2 - Rf^2) form.
@@ -478,6 +481,54 @@ static bool BuildGridLayout(const rt_sphere* sp, uint32_t n, const std::vector<u
     L.gridOn = true;
     L.gridNu = nu; L.gridNv = nv; L.gridAxU = (uint32_t)axU; L.gridAxV = (uint32_t)axV;
     L.gridG0u = g0u; L.gridG0v = g0v; L.gridInvH = invH; L.gridRmaxOverH = (float)(rmax * (double)invH * 1.0001);
+    {   // Quantised bounds (rt_scan.h GridQuant): the device's four fmas, evaluated here with fmaf on the same constants, give the
+        // bound centre C' bit for bit; the radius class covers r_i plus the sphere's own offset |C' - c_i|.
+        const float hF = (float)h, su = hF / 256.f;
+        const float uBase0 = g0u + 0.5f * su, vBase = g0v + 0.5f * su;
+        double wlo = 1e300, whi = -1e300;
+        for (uint32_t k : small) {
+            wlo = std::min(wlo, (double)coord(k, w));
+            whi = std::max(whi, (double)coord(k, w));
+        }
+        const float wstep = (float)((whi - wlo) / 16.0 * 1.0001 + 1e-30), wBase = (float)wlo + 0.5f * wstep;
+        struct Q1 { uint32_t du, v16, kw; double err, r; };
+        std::vector<Q1> q1(keyed.size());
+        double smax = 0.0, Rmax = 0.0;
+        bool ok = true;
+        for (size_t q = 0; q < keyed.size() && ok; ++q) {
+            const uint32_t k = keyed[q].second, cell = keyed[q].first, iu = cell / nv, iv = cell % nv;
+            const double fu = ((double)coord(k, axU) - (double)g0u) * (double)invH - (double)iu;  // position in the home cell, [0, 1) unless clamped
+            const double fv = ((double)coord(k, axV) - (double)g0v) * (double)invH - (double)iv;
+            const uint32_t du = (uint32_t)std::min(255.0, std::max(0.0, std::floor(fu * 256.0)));
+            const uint32_t dv = (uint32_t)std::min(255.0, std::max(0.0, std::floor(fv * 256.0)));
+            const uint32_t kw = (uint32_t)std::min(15.0, std::max(0.0, std::floor(((double)coord(k, w) - wlo) / std::max((double)wstep, 1e-30))));
+            const uint32_t v16 = iv * 256u + dv;
+            const float uBase = std::fmaf((float)iu, hF, uBase0);
+            const float cu = std::fmaf((float)du, su, uBase), cv = std::fmaf((float)v16, su, vBase), cw = std::fmaf((float)kw, wstep, wBase);
+            const double eu = (double)cu - coord(k, axU), ev = (double)cv - coord(k, axV), ew = (double)cw - coord(k, w);
+            const double err = std::sqrt(eu * eu + ev * ev + ew * ew);
+            q1[q] = {du, v16, kw, err, (double)sp[k].r};
+            smax = std::max(smax, err);
+            Rmax = std::max(Rmax, (double)sp[k].r + err);
+        }
+        // (a sphere clamped into an edge cell can sit far from its cell: then the classes would be too coarse to be of use)
+        if (ok && smax > 0.02 * h + 0.5 * (double)wstep) ok = false;
+        if (ok) {
+            const float rstep = (float)(Rmax * (1.0 + 1e-5) / 16.0);
+            L.gridQ.assign(L.scan.size(), 0u);
+            for (size_t q = 0; q < keyed.size(); ++q) {
+                const double need = (q1[q].r + q1[q].err) * (1.0 + 1e-6) + 1e-30;
+                uint32_t kr = 0;
+                while (kr < 15u && (double)std::fmaf((float)kr, rstep, rstep) < need) ++kr;
+                if ((double)std::fmaf((float)kr, rstep, rstep) < need) { ok = false; break; }
+                L.gridQ[base + q] = q1[q].du | q1[q].v16 << 8 | q1[q].kw << 24 | kr << 28;
+            }
+            const float s2 = (float)(smax * smax * (1.0 + 1e-5) + 1e-30);
+            const float qc[8] = {su, uBase0, hF, vBase, wBase, wstep, rstep, s2};
+            for (int c = 0; c < 8; ++c) L.gridQc[c] = qc[c];
+        }
+        if (!ok) L.gridQ.clear();
+    }
     return true;
 }
 
@@ -837,6 +888,18 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     size_t gridBytes = (grid && ctx->blockThreads == 1024) ? (((size_t)tp.grid_nu * tp.grid_nv + 1) * 2 + 15) / 16 * 16 : 0;
     if (candBytes + gridBytes > 160 * 1024) gridBytes = 0;  // (cannot happen below 60,000 cells)
     tp.grid_in_lds = gridBytes ? 1u : 0u;
+    // ... and, RT_GRID_QUANT=1 (experiments; BASELINE configs[4]'s "LDS-tiled sphere list"): in the stash variant with global tables
+    // the QUANTISED one-sphere bounds behind the cells (rt_scan.h GridQuant: the step loop then reads no global memory) when they
+    // leave room for a stash of at least 24 records.  Measured on grid10k (4096^2, spp 64): 40 KB of bounds leave 38 stash records
+    // instead of 63; 7.59 -> 7.10 Gsamples/s, of which -3.8 % is the smaller stash (float4 bounds at 38 records: 7.31) and -2.8 %
+    // the 17 extra operations per tested sphere that unpack the record -- the float4 bounds hit L1 95 % of the time, and what the
+    // L1 serves per cycle was not the limit it looked like (profiles/r04_c5_placement.json).  Default off.
+    size_t gridQBytes = 0;
+    if (grid && !gridLds && gridBytes != 0 && tp.grid_qrec != nullptr && ctx->useStash && carryMode == 0 && ctx->blockThreads == 1024 &&
+        tp.max_depth < 65536u && EnvU32("RT_GRID_QUANT", 0u) != 0u && EnvU32("RT_GRID_SG_LDS", 0u) == 0u && EnvU32("RT_STASH_CAP", 63u) >= 16u) {
+        const size_t qb = ((size_t)tp.n_padded * 4 + 15) / 16 * 16;
+        if (candBytes + gridBytes + qb + (size_t)wavesPerBlock * 24 * rtd::kStashDwords * 4 + 256 <= 160 * 1024) gridQBytes = qb;
+    }
     // cell-grid scan with its tables in global memory, RT_GRID_SG_LDS=1 (experiments): the shadow index in LDS next to the cells when
     // that leaves a stash of at least 24 records.  Measured on grid10k: 48.6 KB of index leave 31 records instead of 63: -5 %
     // (6.47 vs 6.82 Gsamples/s) -- the full stash is worth more than the three dependent L2 reads per shadow query it would save.
@@ -850,7 +913,7 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
             sgBytes = sgb;
         }
     }
-    size_t ldsBytes = candBytes + ((ldsTables || gridLds) ? lds : 0) + ((flat || gridLds) ? leafBytes : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0) + sgBytes + treeBytes + gridBytes;
+    size_t ldsBytes = candBytes + ((ldsTables || gridLds) ? lds : 0) + ((flat || gridLds) ? leafBytes : 0) + ((flat || tree) ? MfmaOpsBytesFor(topCnt) : 0) + sgBytes + treeBytes + gridBytes + gridQBytes;
     // per-wave caches of prepared paths go last, when there is room left (RT_RAY_CACHE=0 disables them)
     ldsBytes = (ldsBytes + 15) / 16 * 16;
     tp.ray_cache_off16 = 0;
@@ -947,6 +1010,8 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     else if (gridLds && tp.grid_in_lds) RT_LAUNCH_K(true, 1024, 3, false, true);
     else if (grid && gridSgLds && useStash && tp.grid_in_lds) RT_LAUNCH_K(false, 1024, 3, true, true, false, true, false, true);
     else if (grid && gridSgLds) return Fail(RT_ERR_HIP, "internal: the grid variant with the shadow index in LDS needs the hit stash");
+    else if (grid && ctx->blockThreads == 1024 && useStash && tp.grid_in_lds && gridQBytes != 0) RT_LAUNCH_K(false, 1024, 3, true, true, false, true, false, false, true);
+    else if (grid && gridQBytes != 0) return Fail(RT_ERR_HIP, "internal: quantised grid bounds without the stash variant");
     else if (grid && ctx->blockThreads == 1024 && useStash && tp.grid_in_lds) RT_LAUNCH_K(false, 1024, 3, true, true, false, true);
     else if (grid && ctx->blockThreads == 1024 && tp.grid_in_lds && tp.ray_cache_off16) RT_LAUNCH_K(false, 1024, 3, true, true);
     else if (grid && ctx->blockThreads == 1024 && tp.grid_in_lds) RT_LAUNCH_K(false, 1024, 3, false, true);
@@ -1264,6 +1329,7 @@ void rt_destroy(rt_ctx* ctx) {
     ctx->tree.Release();
     ctx->sgCells.Release();
     ctx->gridCells.Release();
+    ctx->gridQ.Release();
     ctx->sgEntries.Release();
     ctx->sgGlobal.Release();
     ctx->sgSph.Release();
@@ -1424,6 +1490,10 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     if (L.gridOn) {
         if ((rc = ctx->gridCells.Reserve(L.gridCellStart.size())) != RT_OK) return rc;
         RT_HIP(hipMemcpy(ctx->gridCells.ptr, L.gridCellStart.data(), L.gridCellStart.size() * 2, hipMemcpyHostToDevice));
+        if (!L.gridQ.empty()) {
+            if ((rc = ctx->gridQ.Reserve(L.gridQ.size())) != RT_OK) return rc;
+            RT_HIP(hipMemcpy(ctx->gridQ.ptr, L.gridQ.data(), L.gridQ.size() * 4, hipMemcpyHostToDevice));
+        }
     }
 
     rtd::TraceParams& b = ctx->base;
@@ -1439,6 +1509,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
         b.grid_inv_h = L.gridInvH;
         b.grid_rmax_over_h = L.gridRmaxOverH;
         b.grid_big_norm = L.gridBigNorm;
+        b.grid_qrec = L.gridQ.empty() ? nullptr : ctx->gridQ.ptr;
+        for (int c = 0; c < 8; ++c) b.grid_q[c] = L.gridQc[c];
     }
     b.n_lights = n_lights;
     b.extra_lights = recs.empty() ? nullptr : ctx->lightRecs.ptr;

@@ -100,6 +100,7 @@ struct SceneTabs {
     const float4* tree;
     const uint16_t *sgCell, *sgEntries, *sgGlobal;
     const uint16_t* gridCells;  // cell-grid scan: first scan entry per cell
+    const uint32_t* gridQ;      // ... and (kGridQ) the quantised one-sphere bounds in LDS
     uint32_t nTop, nTiles;
 };
 
@@ -114,10 +115,11 @@ struct SceneTabs {
 // kMatsL2 (with kHitLds): the material table is NOT staged -- it is read through L2 with a global-address-space pointer, and
 // the 48 bytes per sphere it would take go to the hit stash (on the cover scene 44 -> 63 records per wave).
 // kSgLds (cell-grid scan with its tables in global memory): the shadow index is staged behind the cells (typed LDS pointers).
-template <bool kLds, int kScan, bool kHitLds = false, bool kMatsL2 = false, bool kSgLds = false>
+template <bool kLds, int kScan, bool kHitLds = false, bool kMatsL2 = false, bool kSgLds = false, bool kGridQ = false>
 RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
     constexpr bool kMfma = kScan == 1 || kScan == 2;
     T.gridCells = p.grid_cell_start;
+    T.gridQ = nullptr;
     T.scan = p.scan;
     T.orig = p.orig;
     T.leaf = p.leaf;
@@ -210,6 +212,11 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
             const uint32_t ng = p.grid_nu * p.grid_nv + 1u;
             for (uint32_t k = threadIdx.x; k < ng; k += blockDim.x) g[k] = p.grid_cell_start[k];
             T.gridCells = g;
+            if (kGridQ) {  // the quantised bounds behind the cells (16-byte steps): 4 bytes per scan entry
+                uint32_t* q = reinterpret_cast<uint32_t*>(g + ((ng + 7u) & ~7u));
+                for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) q[k] = p.grid_qrec[k];
+                T.gridQ = q;
+            }
             if (kSgLds) {  // the shadow index behind the cells (16-byte steps); the host launches this flavour only when the scene has one
                 uint16_t* sgl = g + ((ng + 7u) & ~7u);
                 const uint32_t nc = p.sg_nx * p.sg_ny + 1u;
@@ -299,8 +306,10 @@ RT_DEV bool claim_block(const TraceParams& p, SceneConsts* ldsK, uint32_t lane, 
 // kLights (trace_body only): false = ONE light, the reference's scene (rt_trace_kernel); true = the scene's LIST of lights
 // (rt_trace_kernel_lights: Material::Shade's loop, material.cpp:4-13).  Two entry kernels over one body, so that the single-light
 // kernels' code and register allocation are exactly what they were without the list.
-template <bool kLights, bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds, bool kCarry, bool kStash, bool kMatsL2, bool kSgLds>
+// kGridQ (cell-grid scan, global tables): the quantised one-sphere bounds are staged into LDS behind the cells (rt_scan.h GridQuant).
+template <bool kLights, bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds, bool kCarry, bool kStash, bool kMatsL2, bool kSgLds, bool kGridQ>
 __device__ __forceinline__ void trace_body(const TraceParams& p) {
+    static_assert(!kGridQ || (kScan == 3 && !kLds && kHitLds && !kSgLds), "quantised bounds: the global-tables grid variant");
     static_assert(!kSgLds || (kScan == 3 && !kLds && kHitLds), "shadow index in LDS next to the grid's cells: the global-tables grid variant");
     static_assert(!kMatsL2 || (kHitLds && kStash && kLds), "materials through L2: a flavour of the all-in-LDS stash variants");
     constexpr bool kMfma = kScan == 1 || kScan == 2;  // matrix-core filter; kScan == 3: cell-grid scan (rt_scan.h scan_list_grid)
@@ -341,7 +350,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& p) {
         }
     float4* tabBase = globSph + p.sg_glob16;
     SceneTabs T;
-    stage_scene<kLds, kScan, kHitLds, kMatsL2, kSgLds>(p, tabBase, T);  // ends with a workgroup barrier when it staged anything
+    stage_scene<kLds, kScan, kHitLds, kMatsL2, kSgLds, kGridQ>(p, tabBase, T);  // ends with a workgroup barrier when it staged anything
     const float4* scanTab = T.scan;
     const uint32_t* origTab = T.orig;
     const float4* leafTab = T.leaf;
@@ -353,6 +362,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& p) {
     const uint16_t* sgEntries = T.sgEntries;
     const uint16_t* sgGlobal = T.sgGlobal;
     const uint16_t* gridCells = T.gridCells;
+    const uint32_t* gridQ = T.gridQ;
     const uint32_t nTop = T.nTop, nTiles = T.nTiles;
 
     const uint32_t lane = threadIdx.x & (kWaveSize - 1);
@@ -835,7 +845,8 @@ __device__ __forceinline__ void trace_body(const TraceParams& p) {
                                        live, tmin, idx, waveCand, lane, dbgScan);
         } else if (kScan == 3) {
             const GridParams G{gridCells, p.grid_nu, p.grid_nv, p.grid_ax_u, p.grid_ax_v, p.grid_g0u, p.grid_g0v, p.grid_inv_h, p.grid_rmax_over_h, p.grid_big_norm};
-            scan_list_grid(scanTab, leafTab, origTab, G, gridCells, p.n_always, p.tree_box, p.bound_norm, ro, rd, live, tmin, idx, waveCand, lane);
+            const GridQuant Q{gridQ, p.grid_q[0], p.grid_q[1], p.grid_q[2], p.grid_q[3], p.grid_q[4], p.grid_q[5], p.grid_q[6], p.grid_q[7]};
+            scan_list_grid<kGridQ>(scanTab, leafTab, origTab, G, gridCells, p.n_always, p.tree_box, p.bound_norm, ro, rd, live, tmin, idx, waveCand, lane, Q);
         } else if (live) {
             scan_list_deferred(scanTab, origTab, p.n_padded, ro, rd, tmin, idx, cand);
         }
@@ -960,15 +971,15 @@ __device__ __forceinline__ void trace_body(const TraceParams& p) {
 }
 
 template <bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds = false, bool kCarry = false, bool kStash = false, bool kMatsL2 = false,
-          bool kSgLds = false>
+          bool kSgLds = false, bool kGridQ = false>
 __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel(const TraceParams p) {
-    trace_body<false, kLds, kThreads, kScan, kCache, kHitLds, kCarry, kStash, kMatsL2, kSgLds>(p);
+    trace_body<false, kLds, kThreads, kScan, kCache, kHitLds, kCarry, kStash, kMatsL2, kSgLds, kGridQ>(p);
 }
 // ... and for scenes whose light list has another length than one (rt_scene_upload, n_lights != 1)
 template <bool kLds, int kThreads, int kScan, bool kCache, bool kHitLds = false, bool kCarry = false, bool kStash = false, bool kMatsL2 = false,
-          bool kSgLds = false>
+          bool kSgLds = false, bool kGridQ = false>
 __global__ void __launch_bounds__(kThreads, 1) rt_trace_kernel_lights(const TraceParams p) {
-    trace_body<true, kLds, kThreads, kScan, kCache, kHitLds, kCarry, kStash, kMatsL2, kSgLds>(p);
+    trace_body<true, kLds, kThreads, kScan, kCache, kHitLds, kCarry, kStash, kMatsL2, kSgLds, kGridQ>(p);
 }
 
 // ============================================================ ray-generation tables (A1, A9)

@@ -148,6 +148,10 @@ struct TraceParams {
     const uint16_t* grid_cell_start;  // [grid_nu * grid_nv + 1] first scan entry of each cell, or null: no grid for this scene
     uint32_t grid_nu, grid_nv, grid_ax_u, grid_ax_v, grid_in_lds;
     float grid_g0u, grid_g0v, grid_inv_h, grid_rmax_over_h, grid_big_norm;
+    // ... and its QUANTISED one-sphere bounds (rt_scan.h GridQuant): 4 bytes per scan entry, staged into LDS by the kGridQ kernels, so that the
+    // step loop's conservative tests read no global memory; null: the scene has none (the float4 bounds `leaf` are read through L1/L2)
+    const uint32_t* grid_qrec;
+    float grid_q[8];                  // su, uBase0, h, vBase, wBase, wstep, rstep, s_max^2 (GridQuant's constants)
     // Exact shadow index for the (single, directional) sun: spheres binned by their footprint in the plane
     // perpendicular to the light.  Valid for hit points with |p|^2 <= sg_p0sq.
     const uint16_t* sg_cell_start;  // [sg_nx * sg_ny + 1]

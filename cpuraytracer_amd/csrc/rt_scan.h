@@ -1031,6 +1031,32 @@ struct GridParams {
     float rmaxOverH;            // largest radius among the grid's spheres, in cells
     float bigNorm;              // max |c| + r over the big spheres (the scale of their bounds' behind-the-origin threshold)
 };
+// QUANTISED one-sphere bounds of the grid's small spheres: 4 bytes per scan entry, in LDS (40 KB for 10,004 spheres).
+//   byte 0      du   position in the slab's u-extent:   cu' = fma(du, su, fma(iu, h, uBase0)),  su = h / 256, uBase0 = g0u + su / 2
+//   bytes 1-2   v16  = iv * 256 + dv, position in v:     cv' = fma(v16, su, vBase),              vBase = g0v + su / 2
+//   bits 24-27  kw   position on the layer's thin axis:  cw' = fma(kw, wstep, wBase)
+//   bits 28-31  kr   radius class, rounded UP:           R'  = fma(kr, rstep, rstep)
+// (u, v, w) are the scene's coordinates permuted so that u, v span the grid; the test runs in that order (dot products do not
+// care).  The host evaluates the same four fmas (fmaf: the same bits) and picks kr so that R' >= r_i + |C' - c_i|: the sphere
+// (C', R') CONTAINS sphere i, its centre is off by s_i <= s_max.  Conservativeness, as for every bound: a positive
+// reference discriminant puts the line within sqrt(r_i^2 + E/a) of c_i, hence within s_i + that of C'; against R' >= s_i + r_i the
+// true bound discriminant exceeds -(E + 2 s_i sqrt(a E)) >= -(2E + a s_i^2) (AM-GM with weight 1: s_i is tiny here, where the
+// group bounds' 101 E + 0.01 a s^2 paid for large offsets).  2E <= 32 eps a G plus the filter's own arithmetic (<= 30 eps a G) is
+// inside K = 64, the one-sphere margin; a s_max^2 goes into Rf^2:
+//   Rf^2 = R'^2 (1 + 1e-5) + s_max^2 + 64 eps (2 (|C'| + R')^2 + R'^2),  with 2 (|C'| + R')^2 + R'^2 <= 4 |C'|^2 + 5 R'^2
+//   W'   = |C'|^2 - Rf^2 >= |C'|^2 (1 - 264 eps) - R'^2 (1 + 1e-5 + 320 eps) - s_max^2     (8 eps |C'|^2: the rounding of W' itself)
+struct GridQuant {
+    const uint32_t* rec;  // LDS
+    float su, uBase0, h, vBase, wBase, wstep, rstep, s2;
+};
+RT_DEV float4 grid_quant_bound(uint32_t rec, float uBase, const GridQuant& Q) {
+    const float fu = (float)(rec & 255u), fv = (float)((rec >> 8) & 0xffffu), fw = (float)((rec >> 24) & 15u), fr = (float)(rec >> 28);
+    const float cu = __builtin_fmaf(fu, Q.su, uBase), cv = __builtin_fmaf(fv, Q.su, Q.vBase), cw = __builtin_fmaf(fw, Q.wstep, Q.wBase);
+    const float R = __builtin_fmaf(fr, Q.rstep, Q.rstep);
+    const float c2 = __builtin_fmaf(cw, cw, __builtin_fmaf(cv, cv, cu * cu));
+    const float w = __builtin_fmaf(c2, 1.f - 264.f * 5.9604645e-8f, __builtin_fmaf(R * R, -(1.f + 1e-5f + 320.f * 5.9604645e-8f), -Q.s2));
+    return make_float4(cu, cv, cw, w);
+}
 #ifndef RT_GRID_DRAIN
 #define RT_GRID_DRAIN 32
 #endif
@@ -1085,9 +1111,11 @@ RT_DEV void grid_slab_rows(float su, float sv, float eu, float ev, float D, floa
     if (f1 < 0.f) r1 = -1;
 }
 
+// kQ: the step loop tests the QUANTISED bounds from LDS (GridQuant above) instead of the float4 bounds `leaf` from global memory.
+template <bool kQ = false>
 RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restrict__ leaf, const uint32_t* __restrict__ orig,
                            const GridParams G, const uint16_t* __restrict__ cellStart, uint32_t nAlways, const float* treeBox, float boundNorm,
-                           V3 o, V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand, uint32_t lane) {
+                           V3 o, V3 d, bool live, float& tmin, int& idx, uint16_t* waveCand, uint32_t lane, const GridQuant Q = GridQuant{}) {
     RT_SITE(G_SCAN);
     const float a = dot3(d, d);
     tmin = __builtin_inff();
@@ -1095,6 +1123,11 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
     const float dO = dot3(d, o);
     const float m2a = -2.f * a;
     const float gx = m2a * o.x, gy = m2a * o.y, gz = m2a * o.z;
+    // kQ: the quantised bounds live in (u, v, w) = the scene's axes permuted so that u, v span the grid; the owner lane hands out
+    // its ray's g and d in that order (the products of a dot product commute; the filter's rounding is inside every margin)
+    const uint32_t axW = 3u - G.axU - G.axV;
+    const float guQ = G.axU == 0u ? gx : (G.axU == 1u ? gy : gz), gvQ = G.axV == 0u ? gx : (G.axV == 1u ? gy : gz), gwQ = axW == 0u ? gx : (axW == 1u ? gy : gz);
+    const float duQ = G.axU == 0u ? d.x : (G.axU == 1u ? d.y : d.z), dvQ = G.axV == 0u ? d.x : (G.axV == 1u ? d.y : d.z), dwQ = axW == 0u ? d.x : (axW == 1u ? d.y : d.z);
     const float oo = dot3(o, o);
     const float aoo = a * oo;
     const float bt = 1e-4f * __builtin_sqrtf(a) * (__builtin_sqrtf(oo) + boundNorm);
@@ -1235,9 +1268,10 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
             const uint32_t ent = has ? work[base + lane] : 0u;
             const uint32_t r = ent >> 8;
             const int iu = (int)(ent & 255u);
-            const V3 fg = v3(lane_fetch(r, gx), lane_fetch(r, gy), lane_fetch(r, gz));
-            const V3 fd = v3(lane_fetch(r, d.x), lane_fetch(r, d.y), lane_fetch(r, d.z));
+            const V3 fg = kQ ? v3(lane_fetch(r, guQ), lane_fetch(r, gvQ), lane_fetch(r, gwQ)) : v3(lane_fetch(r, gx), lane_fetch(r, gy), lane_fetch(r, gz));
+            const V3 fd = kQ ? v3(lane_fetch(r, duQ), lane_fetch(r, dvQ), lane_fetch(r, dwQ)) : v3(lane_fetch(r, d.x), lane_fetch(r, d.y), lane_fetch(r, d.z));
             const float fa = lane_fetch(r, a), fdO = lane_fetch(r, dO), fcr = lane_fetch(r, crLeaf), fbt = lane_fetch(r, bt);
+            const float uBaseQ = kQ ? __builtin_fmaf((float)iu, Q.h, Q.uBase0) : 0.f;  // the slab's u origin (GridQuant)
             const float fsu = lane_fetch(r, su), fsv = lane_fetch(r, sv), feu = lane_fetch(r, eu), fev = lane_fetch(r, ev), fD = lane_fetch(r, D);
             const float fsl = lane_fetch(r, gSlope), fiv = lane_fetch(r, gInvDu);
             const float ftn = lane_fetch(r, tn), ftf = lane_fetch(r, tf);
@@ -1264,7 +1298,8 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
 #pragma unroll
                 for (uint32_t q = 0; q < kGridStep; ++q) {
                     const uint32_t e = eb + q;
-                    const float4 B = leaf[e < ee ? e : 0u];  // (entry 0 is always there; its result is masked)
+                    // (entry 0 is always there; its result is masked)
+                    const float4 B = kQ ? grid_quant_bound(Q.rec[e < ee ? e : 0u], uBaseQ, Q) : leaf[e < ee ? e : 0u];
                     const int rej = e < ee ? bound_rejected_span(B, fg, fd, fa, fdO, fcr, fbt, fun, fu) : -1;
                     rb = __builtin_amdgcn_alignbit(rb, (uint32_t)rej, 31);
                 }

@@ -17,6 +17,10 @@ Usage: python tests/golden/make_full_size_golden.py [c2 c3 c4 c5] [--threads N]
 every scan, 2.3e11 sphere tests per C2 job) and compare with the recorded digest made through PaddedListTree; on equality
 the record gets "list_verified": true (+ the seconds it took); on a mismatch the script says so and exits 1 without
 touching the record -- the digest, not the GPU, is then what has to be fixed first.
+       python tests/golden/make_full_size_golden.py --accel list --rows 2016:2080 c5
+--rows a:b (with --accel list): render only image rows [a, b) at full width and full spp with the plain list and compare their
+per-row CRC32s with the recorded ones (C5's whole job through the plain list is 4.6e13 sphere tests; a band is minutes); on
+equality the record gets "list_verified_rows": [[a, b], ...].
 """
 import hashlib
 import json
@@ -64,6 +68,11 @@ def main():
     if "--threads" in sys.argv:
         threads = int(sys.argv[sys.argv.index("--threads") + 1])
         args = [a for a in args if a != str(threads)]
+    rows = None
+    if "--rows" in sys.argv:
+        spec = sys.argv[sys.argv.index("--rows") + 1]
+        rows = tuple(int(x) for x in spec.split(":"))
+        args = [a for a in args if a != spec]
     verify_list = False
     if "--accel" in sys.argv:
         mode = sys.argv[sys.argv.index("--accel") + 1]
@@ -80,6 +89,23 @@ def main():
         sc = O.build_scene(scene, sseed, W / H, ap)
         orc.upload(sc)
         t = time.time()
+        if verify_list and rows is not None:
+            rs = O.RtRowset(rows[0], rows[1] - rows[0], rows[1] - rows[0], 0, 1)
+            orc.render(W, H, 1, 1 + spp, depth, rseed, rowset=rs, accel=O.ACCEL_LIST, threads=threads)
+            hdr, _ = orc.download()
+            hdr = np.ascontiguousarray(hdr, dtype="<f4")
+            rec = out[name]
+            got = [zlib.crc32(hdr[k].tobytes()) for k in range(hdr.shape[0])]
+            same = got == rec["hdr_row_crc32"][rows[0]:rows[1]]
+            print(name, "plain list, rows %d..%d:" % (rows[0], rows[1] - 1), "EQUAL" if same else "DIFFERENT", round(time.time() - t, 1), "s", flush=True)
+            if not same:
+                bad += 1
+                continue
+            rec.setdefault("list_verified_rows", []).append([rows[0], rows[1]])
+            with open(OUT, "w") as f:
+                json.dump(out, f, indent=0, sort_keys=True)
+                f.write("\n")
+            continue
         if verify_list:
             st = orc.render(W, H, 1, 1 + spp, depth, rseed, accel=O.ACCEL_LIST, threads=threads)
             orc.resolve()

@@ -115,6 +115,31 @@ def test_whole_frames_equal_the_live_oracle(hip, oracle, scenes_mod, name, spp):
         _assert_matches_digest(name, so, ho, lo)
 
 
+@pytest.mark.parametrize("name,row0,nrows", [("c4", 620, 48), ("c5", 2016, 64), ("c3", 520, 16)])
+def test_digest_rows_are_reproduced_by_the_live_oracle_at_full_spp(hip, oracle, scenes_mod, name, row0, nrows):
+    """the C3 / C4 / C5 digests were made in the build container; here the oracle renders a BAND of rows of the same
+    job at FULL spp on this box (rows through the middle of the sphere layer: the busiest part of the picture) and must reproduce
+    the committed per-row CRC32s of exactly those rows -- and so must the GPU's render of the band alone (a row shard of the job)."""
+    import cpuraytracer_amd as pkg
+    rec = DIGESTS[name]
+    W, H, spp = rec["W"], rec["H"], rec["spp"]
+    sc = _scene_for(scenes_mod, rec)
+    rs_o = oracle.RtRowset(row0, nrows, nrows, 0, 1)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    so = orc.render(W, H, 1, 1 + spp, rec["depth"], rec["render_seed"], rowset=rs_o, accel=oracle.ACCEL_PADDED_LIST, threads=THREADS)
+    ho, _ = orc.download()
+    orc.close()
+    ho = np.ascontiguousarray(ho, dtype="<f4")
+    want = rec["hdr_row_crc32"][row0:row0 + nrows]
+    assert [zlib.crc32(ho[k].tobytes()) for k in range(nrows)] == want, "%s: the live oracle's rows %d..%d differ from the committed digest" % (name, row0, row0 + nrows - 1)
+    hip.upload(sc)
+    sg = hip.render(W, H, 1, 1 + spp, rec["depth"], rec["render_seed"], rowset=pkg._capi.RtRowset(row0, nrows, nrows, 0, 1))
+    hg = np.ascontiguousarray(hip.download(ldr=False)[0], dtype="<f4")
+    assert [zlib.crc32(hg[k].tobytes()) for k in range(nrows)] == want
+    assert (sg.samples, sg.traversals, sg.segments) == (so.samples, so.traversals, so.segments)
+
+
 @pytest.mark.parametrize("name,n", [("c4", 2_000_000), ("c5", 2_000_000), ("c2", 1_000_000)])
 def test_millions_of_random_samples_equal_the_live_oracle(hip, oracle, scenes_mod, name, n):
     """rt_unit_trace (the production launch with a caller-given list of paths) against orc_unit_trace on n random

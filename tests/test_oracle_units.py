@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 
 def f32(x):
@@ -450,6 +450,33 @@ def test_padded_list_tree_is_the_list_scan(oracle, name, n_random, n_grazing):
     assert (hl[:, 1].view(np.int32) >= 0).sum() > len(rays) // 4
     lost = int(((hl[:, 1].view(np.int32) >= 0) & (hb[:, 1].view(np.int32) != hl[:, 1].view(np.int32))).sum())
     print("%s: BvhNode differs from the list on %d of %d rays" % (name, lost, len(rays)))
+
+
+def test_padded_list_tree_on_harvested_queries_of_c5(oracle):
+    """The rays the C5 job really casts (tools/harvest_accel_queries.py: random samples of the 4096 x 4096 x 64 job traced with every
+    accelerator query recorded) give the same hit record through the plain list and through PaddedListTree, and what the paths saw
+    equals the list's answer.  200,000 queries here; profiles/r04_accel_query_replay_c5.json holds the 1.2e7-query run."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("harvest_accel_queries", os.path.join(ROOT, "tools", "harvest_accel_queries.py"))
+    hv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hv)
+    sc = oracle.build_scene("grid10k", 1, 1.0)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    q = hv.harvest(orc, 4096, 4096, 64, 200000, 8, rng_seed=99)
+    rep = hv.replay(orc, q, 8)
+    assert rep["queries"] >= 200000 and rep["list_hits"] > 50000 and rep["occlusion_queries"] > 40000
+    assert rep["records_differing_list_vs_padded_list"] == 0
+    assert rep["recorded_closest_t_differing_from_list"] == 0 and rep["recorded_occlusion_differing_from_list"] == 0
+
+
+def test_committed_digests_record_their_plain_list_verification():
+    """Round 4: the digests of every cover-scene job (C2, its two extra scenes, C3, C4) were reproduced with the PLAIN list
+    (tests/golden/make_full_size_golden.py --accel list: the whole job, every sphere for every scan); C5 on a band of rows."""
+    d = json.load(open(os.path.join(GOLDEN, "full_size_oracle_digests.json")))
+    for name in ("c2", "c2_scene2", "c2_scene3_seed7", "c3", "c4"):
+        assert d[name].get("list_verified") is True and "ACCEL_LIST" in d[name]["list_oracle"], name
+    assert d["c5"].get("list_verified_rows"), "run make_full_size_golden.py --accel list --rows a:b c5"
 
 
 def test_known_paths_where_the_reference_bvh_is_not_the_list(oracle):
