@@ -2094,6 +2094,22 @@ int rt_unit_layout(const rt_sphere* spheres, uint32_t n, uint32_t cap_groups, ui
     return RT_OK;
 }
 
+// Host-only: the grid walk's row computation, the SAME functions the kernels call (rt_scan.h; RT_DEV is __host__ __device__).
+int rt_unit_grid_rows(const float* segments, const int32_t* iu, uint32_t n, int32_t nv, int32_t* out_rows, float* out_s_enter) {
+    if (!segments || !iu || !out_rows || nv <= 0) return Fail(RT_ERR_INVALID_ARG, "rt_unit_grid_rows: invalid argument");
+    for (uint32_t k = 0; k < n; ++k) {
+        const float* q = segments + 5 * (size_t)k;
+        float slope, invAbsDu, sEnter;
+        rtd::grid_segment_slope(q[0], q[1], q[2], q[3], slope, invAbsDu);
+        int r0, r1;
+        rtd::grid_slab_rows(q[0], q[1], q[2], q[3], q[4], slope, invAbsDu, (int)iu[k], (int)nv, r0, r1, sEnter);
+        out_rows[2 * k] = r0;
+        out_rows[2 * k + 1] = r1;
+        if (out_s_enter) out_s_enter[k] = sEnter;
+    }
+    return RT_OK;
+}
+
 int rt_unit_layout_info(const rt_sphere* spheres, uint32_t n, uint32_t out[5]) {
     if (!spheres || n == 0 || !out) return Fail(RT_ERR_INVALID_ARG, "rt_unit_layout_info: invalid argument");
     SceneLayout L;

@@ -263,6 +263,10 @@ int rt_unit_layout(const rt_sphere* spheres, uint32_t n, uint32_t cap_groups, ui
  * 2 bounds hierarchy; out[1], out[2] = grid cells along its two axes (0 otherwise); out[3] = big spheres tested for every ray;
  * out[4] = levels of bounds.  Needs no GPU. */
 int rt_unit_layout_info(const rt_sphere* spheres, uint32_t n, uint32_t out[5]);
+/* The cell-grid scan's walk as SHIPPED (csrc/rt_scan.h grid_segment_slope + grid_slab_rows, compiled for the host from the same
+ * source the kernels use): for n segments (su, sv, eu, ev, D: 5 floats each, grid coordinates) and slabs iu, the rows [r0, r1] of
+ * slab iu the walk visits (r0 > r1: none) and the entry parameter sEnter.  out_rows: 2 ints per query.  Needs no GPU. */
+int rt_unit_grid_rows(const float* segments, const int32_t* iu, uint32_t n, int32_t nv, int32_t* out_rows, float* out_s_enter);
 /* The resolve of spheres-app.cpp:196-214 for given HDR triples -> R,G,B bytes */
 int rt_unit_tonemap(rt_ctx* ctx, const float* hdr_rgb, uint32_t n, uint32_t n_samples, uint8_t* out_rgb);
 

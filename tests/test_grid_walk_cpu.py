@@ -2,10 +2,26 @@
 operation: the set of cells it visits for a segment must contain EVERY cell within D cells (Chebyshev) of the segment — that
 is what makes the grid scan's candidate set conservative: the hit point of an accepted root lies on the clipped segment and
 within r + reach of its sphere's centre, so the sphere's home cell is within D = (r_max + reach) / h of the segment.  No GPU."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
 F = np.float32
+
+
+def shipped_slab_rows(queries, ius, nv):
+    """grid_segment_slope + grid_slab_rows AS SHIPPED: librt_hip.so's rt_unit_grid_rows runs the very functions of csrc/rt_scan.h
+    (compiled for the host; no GPU needed), so an edit to them -- kGridSlack, the padding, the clamps -- meets these tests."""
+    from cpuraytracer_amd import _capi
+    L = _capi.load()
+    L.rt_unit_grid_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p]
+    q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 5)
+    iu = np.ascontiguousarray(ius, dtype=np.int32)
+    rows = np.zeros((q.shape[0], 2), dtype=np.int32)
+    se = np.zeros(q.shape[0], dtype=np.float32)
+    assert L.rt_unit_grid_rows(q.ctypes.data, iu.ctypes.data, q.shape[0], nv, rows.ctypes.data, se.ctypes.data) == 0
+    return rows, se
 SLACK = F(1e-3)
 
 
@@ -39,14 +55,19 @@ def slab_rows(su, sv, eu, ev, D, iu, nv):
 
 
 def walk(su, sv, eu, ev, D, nu, nv):
+    """The slabs the feed of scan_list_grid lists, with the rows of each from the SHIPPED grid_slab_rows -- which must also equal
+    the operation-by-operation model above (the model is the documentation; the shipped function is what is tested)."""
     fa = np.floor(F(F(min(su, eu) - D) - SLACK))
     fb = np.floor(F(F(max(su, eu) + D) + SLACK))
     iuA = 0 if fa < 0 else int(fa)
     iuB = nu - 1 if fb > nu - 1 else int(fb)
     cells = set()
     if iuA <= iuB and fb >= 0:
-        for iu in range(iuA, iuB + 1):
-            r0, r1 = slab_rows(su, sv, eu, ev, D, iu, nv)
+        ius = list(range(iuA, iuB + 1))
+        rows, _ = shipped_slab_rows([[su, sv, eu, ev, D]] * len(ius), ius, nv)
+        for iu, (r0, r1) in zip(ius, rows.tolist()):
+            m0, m1 = slab_rows(su, sv, eu, ev, D, iu, nv)
+            assert (r0 > r1 and m0 > m1) or (r0, r1) == (m0, m1), ("shipped grid_slab_rows differs from its model", su, sv, eu, ev, D, iu)
             for iv in range(r0, r1 + 1):
                 cells.add((iu, iv))
     return cells

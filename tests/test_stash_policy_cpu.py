@@ -9,7 +9,12 @@ in the stash — with `break` in place of `continue` below, four of these parame
   * a push only ever happens into an EMPTY stash and never exceeds its capacity;
   * hits are processed by more than `cap` lanes while fresh paths remain.
 
-No GPU: this is the exit condition every wave reaches, stated as a test."""
+No GPU: this is the exit condition every wave reaches, stated as a test.
+
+NOTE: this file exercises a MODEL of the policy, written from rt_kernels.h; an edit to the kernel's push / pop /
+process order does not run through it.  It documents the invariants; the authority for the shipped code are the GPU regression
+tests -- test_hits_left_in_the_stash_when_every_lane_finishes_are_not_lost, the stash-capacity knobs of
+test_launch_and_layout_knobs_give_the_same_bits / test_hierarchy_scan_knobs_give_the_same_bits, and the full-size digests."""
 import random
 
 import pytest
