@@ -51,7 +51,7 @@ RT_SAMPLER_COSINE_HEMISPHERE, RT_SAMPLER_SQRT_DISK = 1, 2
 
 # every symbol include/rt_api.h declares
 EXPORTS = [
-    "rt_last_error", "rt_api_version", "rt_create", "rt_destroy", "rt_set_stream", "rt_set_workspace_limit", "rt_set_sampler", "rt_set_frame_pipelining", "rt_set_frame_batch", "rt_committed_samples",
+    "rt_last_error", "rt_api_version", "rt_create", "rt_destroy", "rt_set_stream", "rt_set_workspace_limit", "rt_set_sampler", "rt_set_frame_pipelining", "rt_set_frame_batch", "rt_set_frame_lookahead", "rt_committed_samples",
     "rt_scene_upload", "rt_render", "rt_clear", "rt_resolve", "rt_last_resolve_ms", "rt_download", "rt_copy_to_device",
     "rt_synchronize", "rt_rowset_local_rows", "rt_rowset_global_row", "rt_unit_halton", "rt_unit_math",
     "rt_unit_primary_rays", "rt_unit_closest_hit", "rt_unit_trace", "rt_unit_camera_rays", "rt_unit_scatter", "rt_unit_tonemap", "rt_unit_layout", "rt_unit_layout_info", "rt_unit_grid_rows",
@@ -86,6 +86,7 @@ def load():
     L.rt_set_frame_pipelining.argtypes = [C.c_void_p, C.c_uint32]
     L.rt_set_frame_batch.argtypes = [C.c_void_p, C.c_uint32]
     L.rt_committed_samples.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.rt_set_frame_lookahead.argtypes = [C.c_void_p, C.c_uint32]
     L.rt_scene_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(RtCamera), C.POINTER(RtLight), C.c_uint32,
                                   C.POINTER(RtMaterial), C.c_float]
     L.rt_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, RtRowset, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,

@@ -153,6 +153,13 @@ struct rt_ctx {
     uint32_t pendW = 0, pendH = 0, pendS0 = 0, pendS1 = 0, pendDepth = 0;
     rt_rowset pendRs{};
     uint64_t pendSeed = 0;
+    // render-ahead (rt_set_frame_lookahead): sample planes [aheadBase, aheadBase + aheadSpp) of the running accumulation sit in the
+    // sample buffer, traced by ONE launch; planes below aheadNext have been added to the strip
+    uint32_t lookahead = 1;
+    bool aheadValid = false;
+    uint32_t aheadW = 0, aheadH = 0, aheadBase = 0, aheadSpp = 0, aheadNext = 0, aheadDepth = 0;
+    rt_rowset aheadRs{};
+    uint64_t aheadSeed = 0;
     uint32_t pipeMaxDepth = 0;  // max_depth and seed of the running pipeline (a flush re-launches with them)
     uint64_t pipeSeed = 0;
     rtd::RegionTable pipeRegions{};
@@ -1379,6 +1386,7 @@ int rt_set_stream(rt_ctx* ctx, void* hip_stream) {
         const int rcf = PipelineFlush(ctx);
         if (rcf != RT_OK) return rcf;
     }
+    ctx->aheadValid = false;  // (planes traced ahead were produced on the old stream)
     ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->ownStream;
     return RT_OK;
 }
@@ -1567,6 +1575,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     b.exposure = exposure_scale;
     ctx->n = n;
     ctx->hasScene = true;
+    ctx->aheadValid = false;
     ctx->accumulated = 0;
     PipelineDrop(ctx);
     return RT_OK;
@@ -1610,6 +1619,7 @@ int rt_set_sampler(rt_ctx* ctx, uint32_t flags) {
 int rt_clear(rt_ctx* ctx) {
     if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_clear: null ctx");
     ctx->pendOn = false;
+    ctx->aheadValid = false;
     PipelineDrop(ctx);
     ctx->accumulated = 0;
     return RT_OK;
@@ -1623,7 +1633,7 @@ uint32_t rt_rowset_global_row(rt_rowset rs, uint32_t lr) {
 }
 
 static int RenderNow(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1, uint32_t max_depth, uint64_t seed,
-                     rt_stats* out_stats);
+                     rt_stats* out_stats, uint32_t aheadEnd = 0);
 
 // Frame batching: render the pending sample planes with ONE launch (no statistics, nothing waits for the device).
 static int BatchFlush(rt_ctx* ctx) {
@@ -1646,9 +1656,33 @@ int rt_set_frame_batch(rt_ctx* ctx, uint32_t frames) {
     return rc;
 }
 
+int rt_set_frame_lookahead(rt_ctx* ctx, uint32_t frames) {
+    if (!ctx || frames == 0 || frames > 4096) return Fail(RT_ERR_INVALID_ARG, "rt_set_frame_lookahead: frames must be 1..4096");
+    ctx->lookahead = frames;
+    ctx->aheadValid = false;
+    return RT_OK;
+}
+
 int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1, uint32_t max_depth, uint64_t seed,
               rt_stats* out_stats) {
     if (!ctx) return Fail(RT_ERR_INVALID_ARG, "rt_render: null ctx");
+    if (ctx->lookahead > 1 && ctx->batchFrames <= 1 && ctx->pipeDepth == 0 && out_stats == nullptr && ctx->hasScene && W != 0 && H != 0 && s0 != 0 && s1 > s0) {
+        // render-ahead: the planes of this call may have been traced by an earlier call's launch -- then they are only ADDED
+        // (in sample order, as always); else this call's launch traces its own planes and the next `lookahead` ones with them
+        if (ctx->aheadValid && ctx->aheadW == W && ctx->aheadH == H && std::memcmp(&ctx->aheadRs, &rs, sizeof(rs)) == 0 && ctx->aheadDepth == max_depth &&
+            ctx->aheadSeed == seed && s0 == ctx->aheadNext && s1 <= ctx->aheadBase + ctx->aheadSpp && ctx->accumulated + 1 == s0) {
+            RT_HIP(hipSetDevice(ctx->device));
+            const uint32_t npix = ctx->W * ctx->rows;
+            hipLaunchKernelGGL(rtd::rt_accumulate_kernel, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, ctx->samples.ptr, ctx->hdr.ptr, npix,
+                               ctx->aheadSpp, s0 - ctx->aheadBase, s1 - s0);
+            RT_HIP(hipGetLastError());
+            ctx->aheadNext = s1;
+            ctx->accumulated += s1 - s0;
+            return RT_OK;
+        }
+        const uint32_t want = s1 - s0 > ctx->lookahead ? s1 - s0 : ctx->lookahead;
+        return RenderNow(ctx, W, H, rs, s0, s1, max_depth, seed, nullptr, s0 + want);
+    }
     if (ctx->batchFrames > 1 && out_stats == nullptr && ctx->pipeDepth == 0 && ctx->hasScene && W != 0 && H != 0 && s0 != 0 && s1 > s0) {
         // a pending batch this call does not continue is rendered first, as the calls were made
         if (ctx->pendOn && !(ctx->pendW == W && ctx->pendH == H && std::memcmp(&ctx->pendRs, &rs, sizeof(rs)) == 0 && ctx->pendDepth == max_depth &&
@@ -1677,8 +1711,11 @@ int rt_render(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, ui
     return RenderNow(ctx, W, H, rs, s0, s1, max_depth, seed, out_stats);
 }
 
+// aheadEnd (render-ahead, rt_set_frame_lookahead): trace the planes [s0, aheadEnd) with this call's ONE launch, add only [s0, s1)
+// to the strip and keep the rest in the sample buffer for the calls that continue (0: trace [s0, s1) only).
 static int RenderNow(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t s0, uint32_t s1, uint32_t max_depth, uint64_t seed,
-                     rt_stats* out_stats) {
+                     rt_stats* out_stats, uint32_t aheadEnd) {
+    ctx->aheadValid = false;  // whatever was traced ahead belongs to the calls before this one
     if (!ctx->hasScene) return Fail(RT_ERR_NO_SCENE, "rt_render: no scene uploaded");
     if (W == 0 || H == 0 || s0 == 0 || s1 <= s0) return Fail(RT_ERR_INVALID_ARG, "rt_render: empty image or sample range");
     const uint32_t rows = RowsetLocalRows(rs);
@@ -1735,7 +1772,9 @@ static int RenderNow(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t
     if (sppMax > sppPathCap) sppMax = sppPathCap;
     if (sppMax == 0) return Fail(RT_ERR_OUT_OF_MEMORY, "rt_render: workspace limit below one sample per pixel");
     const uint32_t sppTotal = s1 - s0;
-    uint32_t sppPass = (uint32_t)(sppMax < sppTotal ? sppMax : sppTotal);
+    if (aheadEnd <= s1 || (uint64_t)(aheadEnd - s0) > sppMax || pipelined) aheadEnd = 0;  // the planes traced ahead must share one pass
+    const uint32_t sppTrace = aheadEnd ? aheadEnd - s0 : sppTotal;
+    uint32_t sppPass = (uint32_t)(sppMax < sppTrace ? sppMax : sppTrace);
     int rc;
     // The default limit is a snapshot of the free memory at rt_create; another context or the caller's allocator may have
     // taken memory since.  A smaller sample buffer only means more passes (bit-identical: the accumulation stays sequential
@@ -1752,8 +1791,9 @@ static int RenderNow(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t
     auto runPasses = [&]() -> int {
         int rc;
         RT_HIP(hipMemsetAsync(ctx->counters.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
-        for (uint32_t s = s0; s < s1; s += sppPass) {
-            const uint32_t spp = (s1 - s) < sppPass ? (s1 - s) : sppPass;
+        const uint32_t sEnd = aheadEnd ? aheadEnd : s1;
+        for (uint32_t s = s0; s < sEnd; s += sppPass) {
+            const uint32_t spp = (sEnd - s) < sppPass ? (sEnd - s) : sppPass;
             rtd::TraceParams tp = ctx->base;
             tp.W = W;
             tp.H = H;
@@ -1794,7 +1834,7 @@ static int RenderNow(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t
             if ((rc = LaunchTrace(ctx, tp)) != RT_OK) return rc;
             RT_HIP(hipEventRecord(ev[1], ctx->stream));
             hipLaunchKernelGGL(rtd::rt_accumulate_kernel, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, ctx->samples.ptr,
-                               ctx->hdr.ptr, npix, spp);
+                               ctx->hdr.ptr, npix, spp, 0u, aheadEnd ? sppTotal : spp);
             RT_HIP(hipGetLastError());
             RT_HIP(hipEventRecord(ev[2], ctx->stream));
             ++passes;
@@ -1807,6 +1847,11 @@ static int RenderNow(rt_ctx* ctx, uint32_t W, uint32_t H, rt_rowset rs, uint32_t
         return rc;
     }
     ctx->accumulated += sppTotal;
+    if (aheadEnd && ctx->samples.ptr && passes == 1) {  // the planes [s1, aheadEnd) wait in the sample buffer
+        ctx->aheadValid = true;
+        ctx->aheadW = W; ctx->aheadH = H; ctx->aheadRs = rs; ctx->aheadDepth = max_depth; ctx->aheadSeed = seed;
+        ctx->aheadBase = s0; ctx->aheadSpp = sppTrace; ctx->aheadNext = s1;
+    }
 
     if (out_stats) {
         // Without a stats request the call stays asynchronous on the stream (progressive 1-spp frames are launch bound:

@@ -1098,17 +1098,19 @@ __global__ void __launch_bounds__(1024) rt_tile_order_kernel(const uint8_t* cls,
 // ============================================================== ordered accumulation (A16)
 // hdr[pixel] += sample(pixel, s) for s = s0 .. s0+spp-1 in that order (spheres-app.cpp:182-183).
 __global__ void __launch_bounds__(256) rt_accumulate_kernel(const float* __restrict__ samples, float* __restrict__ hdr, uint32_t npix,
-                                                            uint32_t spp) {
+                                                            uint32_t spp, uint32_t first = 0, uint32_t count = 0xffffffffu) {
     const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= npix) return;
     float r = hdr[3 * (size_t)pix], g = hdr[3 * (size_t)pix + 1], b = hdr[3 * (size_t)pix + 2];
     // tiled buffer [tile of 64 pixels][sample][pixel in tile] (path_coordinates): the 64 lanes of a wave read 768
-    // contiguous bytes per sample plane; eight planes in flight, the adds stay sequential in s
+    // contiguous bytes per sample plane; eight planes in flight, the adds stay sequential in s.  first / count: the planes
+    // [first, first + count) of the buffer's spp (render-ahead batching adds the planes of one call at a time).
     const uint32_t nFull = npix >> 6, tile = pix >> 6;
     const uint32_t stride = tile < nFull ? 64u : npix - (nFull << 6);
     const float3* sp = reinterpret_cast<const float3*>(samples) + (size_t)tile * 64u * spp + (pix - (tile << 6));
-    uint32_t s = 0;
-    for (; s + 8 <= spp; s += 8) {
+    uint32_t s = first < spp ? first : spp;
+    const uint32_t end = count > spp - s ? spp : s + count;
+    for (; s + 8 <= end; s += 8) {
         float3 v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = sp[(size_t)(s + k) * stride];
@@ -1119,7 +1121,7 @@ __global__ void __launch_bounds__(256) rt_accumulate_kernel(const float* __restr
             b += v[k].z;
         }
     }
-    for (; s < spp; ++s) {
+    for (; s < end; ++s) {
         const float3 v = sp[(size_t)s * stride];
         r += v.x;
         g += v.y;

@@ -49,6 +49,10 @@ class HipRenderer:
         """rt_set_frame_batch: stats-less render calls that continue each other are rendered `frames` sample planes per launch (1 = off)."""
         check(self._L.rt_set_frame_batch(self._h, int(frames)))
 
+    def set_frame_lookahead(self, frames):
+        """rt_set_frame_lookahead: a stats-less render call traces the next `frames` sample planes with its one launch and adds only its own (1 = off)."""
+        check(self._L.rt_set_frame_lookahead(self._h, int(frames)))
+
     def committed_samples(self):
         n = C.c_uint32(0)
         check(self._L.rt_committed_samples(self._h, C.byref(n)))

@@ -201,6 +201,17 @@ int rt_set_frame_pipelining(rt_ctx* ctx, uint32_t depth);
  * continue the batch, rt_scene_upload, rt_set_stream and rt_set_frame_batch itself render what is pending first; errors of
  * deferred calls surface there.  Not combined with rt_set_frame_pipelining (depth > 0 takes precedence).  frames == 1: off. */
 int rt_set_frame_batch(rt_ctx* ctx, uint32_t frames);
+/* Render-AHEAD for progressive use (round 4): with frames > 1, an rt_render call that passes out_stats == NULL traces, with its ONE
+ * launch, its own sample planes AND the planes of the next calls (`frames` planes in all), but adds only its own to the HDR strip;
+ * the calls that continue it (same image, row set, depth and seed; s0 == the previous s1) find their planes traced and only add
+ * them, in sample order -- one small kernel.  The strip always holds EXACTLY the samples of the calls made (display lag 0: what
+ * rt_resolve / rt_download hand out after call f is the one-shot render of samples 1..f, bit for bit), the launch and its tail are
+ * paid once per `frames` calls, and the first call of each group takes the group's time.  A call that does not continue, a call
+ * with statistics, rt_scene_upload, rt_clear, rt_set_stream drop what was traced ahead (nothing of it ever reached the strip).
+ * Why not one frame per launch at full rate: a path is up to 51 dependent scans of ~10 us, five 1200x800 1-spp frames' worth of
+ * bulk-rate work, so a frame's last sample cannot exist before ~5 later frames have been started (interactive mode).
+ * Takes precedence below rt_set_frame_batch and rt_set_frame_pipelining (either of them on: ignored).  frames == 1: off. */
+int rt_set_frame_lookahead(rt_ctx* ctx, uint32_t frames);
 /* Samples per pixel in the HDR strip right now (waits for the stream). */
 int rt_committed_samples(rt_ctx* ctx, uint32_t* out);
 

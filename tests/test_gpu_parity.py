@@ -773,6 +773,57 @@ def test_batched_progressive_frames_equal_the_one_shot_render(hip, scenes_mod, s
         one.close()
 
 
+@pytest.mark.parametrize("scene,W,H,frames,spf,ahead", [("cover", 161, 103, 37, 1, 8), ("cover", 320, 200, 11, 3, 4), ("grid10k", 96, 64, 21, 1, 16),
+                                                    ("three", 65, 1, 9, 1, 2)])
+def test_render_ahead_frames_equal_the_one_shot_render_at_every_frame(hip, scenes_mod, scene, W, H, frames, spf, ahead):
+    """rt_set_frame_lookahead: a stats-less frame traces the next `ahead` sample planes with its one launch and adds only its own;
+    the frames that continue it only add theirs.  After EVERY frame the strip holds exactly the samples of the calls made (display
+    lag 0) and equals the one-shot render of those samples bit for bit; a frame that does not continue (another seed), a call with
+    statistics and a new accumulation drop what was traced ahead without a trace of it in the strip."""
+    from cpuraytracer_amd import HipRenderer
+    sc = scenes_mod.build_scene(scene, 1, W, H)
+    one = HipRenderer(0)
+    one.upload(sc)
+    hip.upload(sc)
+    try:
+        hip.set_frame_lookahead(ahead)
+        for f in range(frames):
+            hip.render(W, H, 1 + f * spf, 1 + (f + 1) * spf, 50, 1, stats=False)
+            assert hip.committed_samples() == (f + 1) * spf
+            if f in (0, 1, ahead - 1, ahead, frames // 2, frames - 1):
+                hip.resolve()
+                h_f, l_f = hip.download()
+                one.render(W, H, 1, 1 + (f + 1) * spf, 50, 1)
+                one.resolve()
+                h_ref, l_ref = one.download()
+                assert_same(h_f, h_ref, "strip after frame %d of %d" % (f + 1, frames))
+                assert_same(l_f, l_ref, "LDR after frame %d" % (f + 1))
+        n0 = frames * spf
+        # a call with statistics continues the accumulation with a launch of its own
+        st = hip.render(W, H, 1 + n0, 2 + n0, 50, 1)
+        assert st.samples == W * H and hip.committed_samples() == n0 + 1
+        one.render(W, H, 1 + n0, 2 + n0, 50, 1)
+        assert_same(hip.download(ldr=False)[0], one.download(ldr=False)[0], "continuation with statistics")
+        # a frame under ANOTHER seed does not continue what was traced ahead: sequence error as without look-ahead? no -- the
+        # sample range continues, so it is rendered, by a launch of its own, with its own seed
+        hip.render(W, H, 2 + n0, 3 + n0, 50, 1, stats=False)   # traces ahead under seed 1
+        hip.render(W, H, 3 + n0, 4 + n0, 50, 9, stats=False)   # seed 9: own launch
+        one.render(W, H, 2 + n0, 3 + n0, 50, 1)
+        one.render(W, H, 3 + n0, 4 + n0, 50, 9)
+        assert_same(hip.download(ldr=False)[0], one.download(ldr=False)[0], "a frame that does not continue the look-ahead")
+        # new accumulation of another size while planes wait in the buffer
+        hip.render(W, H, 4 + n0, 5 + n0, 50, 9, stats=False)
+        W2, H2 = max(8, W // 2), max(1, H // 2)
+        hip.render(W2, H2, 1, 2, 50, 4, stats=False)
+        hip.render(W2, H2, 2, 3, 50, 4, stats=False)
+        assert hip.committed_samples() == 2
+        one.render(W2, H2, 1, 3, 50, 4)
+        assert_same(hip.download(ldr=False)[0], one.download(ldr=False)[0], "new accumulation after a look-ahead")
+    finally:
+        hip.set_frame_lookahead(1)
+        one.close()
+
+
 def test_readers_render_a_pending_batch_that_starts_a_new_picture(hip, scenes_mod):
     """with an accumulation committed, a deferred call with s0 == 1 starts a NEW one -- here of a smaller image.
     rt_resolve / rt_download / rt_copy_to_device must render it first: they used to hand out the OLD strip with the old size into a

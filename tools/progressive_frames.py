@@ -13,11 +13,14 @@ W, H, N = 1200, 800, 256
 sc = scenes.build_scene("cover", 1, W, H)
 one = HipRenderer(0); one.upload(sc); one.render(W, H, 1, N + 1, 50, 1); one.resolve(); h1, _ = one.download()
 MODES = [("pipelining depth", int(x)) for x in os.environ.get("RT_DEPTHS", "0,2,4,8").split(",") if x] + \
-        [("frame batch", int(x)) for x in os.environ.get("RT_BATCHES", "4,8,16,32").split(",") if x]
+        [("frame batch", int(x)) for x in os.environ.get("RT_BATCHES", "4,8,16,32").split(",") if x] + \
+        [("render-ahead", int(x)) for x in os.environ.get("RT_AHEADS", "4,8,16,32").split(",") if x]
 for mode, depth in MODES:
     r = HipRenderer(0); r.upload(sc)
     if mode == "frame batch":
         r.set_frame_batch(depth)
+    elif mode == "render-ahead":
+        r.set_frame_lookahead(depth)
     else:
         r.set_frame_pipelining(depth)
     r.render(W, H, 1, 2, 50, 1, stats=False); r.synchronize()   # warm-up (buffers, LDS attribute)
@@ -32,6 +35,12 @@ for mode, depth in MODES:
         dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
     r.resolve(); hdr, _ = r.download()
-    print("%s %d: %d frames of 1 spp: %.3f ms per frame (%.3f ms host enqueue), %.0f Msamples/s, == one shot: %s"
-          % (mode, depth, N, best / N * 1e3, t_enqueue / N * 1e3, W * H * N / best / 1e6, np.array_equal(hdr.view(np.uint32), h1.view(np.uint32))), flush=True)
+    # display lag: frames made minus samples in the strip, seen by a reader right after frame 100 of a fresh accumulation
+    r.clear()
+    for s in range(1, 101):
+        r.render(W, H, s, s + 1, 50, 1, stats=False)
+    lag = 100 - r.committed_samples()
+    r.synchronize()
+    print("%s %d: %d frames of 1 spp: %.3f ms per frame (%.3f ms host enqueue), %.0f Msamples/s, display lag after frame 100: %d frames, == one shot: %s"
+          % (mode, depth, N, best / N * 1e3, t_enqueue / N * 1e3, W * H * N / best / 1e6, lag, np.array_equal(hdr.view(np.uint32), h1.view(np.uint32))), flush=True)
     r.close()
