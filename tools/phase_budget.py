@@ -26,8 +26,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "cpuraytracer_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
 KERNELS = {  # the instantiation rt_render launches for the config (RT_VERBOSE prints the variant)
-    "c2": "_ZN3rtd15rt_trace_kernelILb1ELi1024ELi1ELb1ELb1ELb0ELb1ELb1ELb0EEEvNS_11TraceParamsE",
-    "c5": "_ZN3rtd15rt_trace_kernelILb0ELi1024ELi3ELb1ELb1ELb0ELb1ELb0ELb0EEEvNS_11TraceParamsE",
+    "c2": "_ZN3rtd15rt_trace_kernelILb1ELi1024ELi1ELb1ELb1ELb0ELb1ELb1ELb0ELb0EEEvNS_11TraceParamsE",
+    "c5": "_ZN3rtd15rt_trace_kernelILb0ELi1024ELi3ELb1ELb1ELb0ELb1ELb0ELb0ELb0EEEvNS_11TraceParamsE",
 }
 WORKLOADS = {"c2": ("cover", 1200, 800, 128, -1.0), "c5": ("grid10k", 4096, 4096, 64, -1.0)}
 SITE_FILES = ("rt_kernels.h", "rt_scan.h", "rt_shade.h", "rt_params.h", "rt_device_math.h")
@@ -42,8 +42,8 @@ PHASES = collections.OrderedDict([
     ("scan: MFMA + mfma_post", ["S_TILEPAIR"]),
     ("scan: one-sphere groups straight to the exact list", ["S_SINGLE", "S_SINGLE_PUSH0", "S_SINGLE_PUSH1"]),
     ("scan: pooled (ray, group) list build", ["S_PASS", "S_TAKE", "S_TAKE_PUSH0", "S_TAKE_PUSH1", "S_PUSH_WORD"]),
-    ("scan: pooled phase A (ray fetch + four one-sphere bound tests + survivor push)", ["S_ASTEP", "S_APUSH"]),
-    ("scan: exact Sphere::Intersect (phase B)", ["S_DRAIN", "S_BSTEP"]),
+    ("scan: pooled phase A (ray fetch + four one-sphere bound tests + survivor push)", ["S_ASTEP", "S_ASTEP2", "S_APUSH"]),
+    ("scan: exact Sphere::Intersect (phase B)", ["S_DRAIN", "S_BSTEP", "S_BSTEP2"]),
     ("scan: ds_min_u64 merge", ["S_BMIN"]),
     ("grid scan: ray clip, big spheres, result read", ["G_SCAN", "G_BIG"]),
     ("grid scan: feed (slab items listed)", ["G_FEED", "G_FEED_LANE"]),
@@ -52,7 +52,7 @@ PHASES = collections.OrderedDict([
     ("grid scan: exact Sphere::Intersect", ["G_DRAIN", "G_BSTEP"]),
     ("grid scan: ds_min_u64 merge", ["G_BMIN"]),
     ("transitions (miss / hit record / far-hit shadow state)", ["K_TRANS_MISS", "K_TRANS_HIT", "K_TRANS_SHADOW"]),
-    ("hit processing: glue (material load, normal, state update)", ["K_PROCESS", "H_PROCESS", "H_INDEXED", "H_FARHIT"]),
+    ("hit processing: glue (material load, normal, state update)", ["K_PROCESS", "H_PROCESS", "H_INDEXED", "H_FARHIT", "H_MULTI"]),
     ("hit processing: scatter_only", ["H_SCATTER", "H_TRANSPARENT", "H_METAL", "H_OPAQUE", "H_OPAQUE_DIFFUSE"]),
     ("hit processing: shadow_query", ["H_SHADOWQ", "H_SQ_WALK", "H_SQ_CONSIDER", "H_SQ_GROUND", "H_SQ_GTAIL", "H_SQ_ROUND", "H_SQ_TAIL1", "H_SQ_CELL", "H_SQ_ROOTS", "H_SQ_FULL"]),
     ("hit processing: shade_value", ["H_SHADEV", "H_SHADE"]),
@@ -141,12 +141,52 @@ def site_regions():
     return regions
 
 
-def innermost_site(regions, fn, line):
+def innermost_site(regions, fn, line, in_lambda=False):
+    """The innermost marked region around (file, line).  in_lambda: the frame is a lambda's operator(); a region whose { } block lies
+    AROUND the lambda's body does not count then -- the lambda runs where it is CALLED (testItem, exactPair, pushWord are defined once
+    and called from differently marked places), so the caller's frame decides; a region inside the lambda's body does count."""
     best = None
     for lo, hi, name in regions.get(fn, ()):
         if lo <= line <= hi and (best is None or hi - lo < best[0]):
-            best = (hi - lo, name)
+            best = (hi - lo, name, lo, hi)
+    if best and in_lambda:
+        for llo, lhi in lambda_bodies(fn):
+            if llo <= line <= lhi and best[2] <= llo and lhi <= best[3] and (best[2], best[3]) != (llo, lhi):
+                return None
     return best[1] if best else None
+
+
+_LAMBDAS = {}
+
+
+def lambda_bodies(fn):
+    """[(first_line, last_line)] of the bodies of the lambdas defined in a source file (`[&](...) ... {` to its `}`)."""
+    if fn not in _LAMBDAS:
+        out = []
+        path = os.path.join(CSRC, fn)
+        if os.path.exists(path):
+            code = strip_code(open(path).read())
+            for m in re.finditer(r"\[&\]\s*\(", code):
+                k = code.find("{", m.end())
+                # the parameter list and attributes come first: the body's brace is the first '{' after the matching ')'
+                depth, j = 1, m.end()
+                while j < len(code) and depth:
+                    depth += code[j] == "("
+                    depth -= code[j] == ")"
+                    j += 1
+                k = code.find("{", j)
+                if k < 0:
+                    continue
+                depth, e = 0, k
+                while e < len(code):
+                    depth += code[e] == "{"
+                    depth -= code[e] == "}"
+                    if depth == 0:
+                        break
+                    e += 1
+                out.append((code.count("\n", 0, k) + 1, code.count("\n", 0, e) + 1))
+        _LAMBDAS[fn] = out
+    return _LAMBDAS[fn]
 
 
 def classify(op):
@@ -231,7 +271,7 @@ def do_static(cfg):
         site, path = None, ()
         for k, (_fn, f, line) in enumerate(fr):  # leaf first
             if line > 0:
-                site = innermost_site(regions, f, line)
+                site = innermost_site(regions, f, line, in_lambda=_fn.startswith("operator()"))
                 if site:
                     path = tuple((ff, ll) for _n, ff, ll in fr[k + 1:])  # the call sites above the matched frame
                     break
@@ -411,6 +451,8 @@ def do_combine(cfg, pmc_path=None):
         print("  %-84s %6.1f wi/sample %7.1f lane-ops/sample  util %s  share %.3f" % (r["phase"], r["valu_wave_instructions_per_sample"] * 64, r["valu_lane_ops_per_sample"],
               ("%.2f" % r["lane_utilisation"]) if r["lane_utilisation"] else " -  ", r["share_of_valu_wave_instructions"]))
     print("  total lane-ops/sample %.1f, lane utilisation %.3f" % (tot_lo / samples, tot_lo / (64.0 * tot_wi)))
+    if missing:
+        print("  regions in no phase:", missing)
     if "pmc_check" in out:
         print("  budget / measured: wave-instructions %.3f, lane-ops %.3f" % (out["pmc_check"]["budget_over_measured_wave_instructions"], out["pmc_check"]["budget_over_measured_lane_ops"]))
     print("  scan statistics:", json.dumps(ss))
