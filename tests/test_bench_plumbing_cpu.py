@@ -41,7 +41,7 @@ def test_roofline_object_is_a_fraction_recomputable_from_the_summary(name):
 
 
 def test_bench_line_committed_with_the_profile_has_the_contract_fields():
-    b = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_line.json")))
+    b = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_line.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline", "cpu_baseline"):
         assert key in b, key
