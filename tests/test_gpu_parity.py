@@ -1128,7 +1128,7 @@ def test_launch_and_layout_knobs_give_the_same_bits(hip, scenes_mod, monkeypatch
                                  {"RT_GRID": "0"}, {"RT_GRID": "0", "RT_TREE_LDS": "0", "RT_STASH": "0"}, {"RT_GRID": "0", "RT_BLOCK_THREADS": "512"},
                                  {"RT_STASH": "0"}, {"RT_STASH": "0", "RT_RAY_CACHE": "0"}, {"RT_BLOCK_THREADS": "256", "RT_BLOCKS_PER_CU": "2"},
                                  {"RT_STASH_CAP": "17"}, {"RT_GRID_SG_LDS": "1"}, {"RT_GRID_QUANT": "1"}, {"RT_GRID_QUANT": "1", "RT_STASH_CAP": "24"},
-                                 {"RT_SHADOW_CELLS": "64"}, {"RT_SHADOW_CELLS": "128", "RT_GRID": "0"}],
+                                 {"RT_SHADOW_CELLS": "64"}, {"RT_SHADOW_CELLS": "128", "RT_GRID": "0"}, {"RT_SG_SPH": "1"}, {"RT_SG_SPH": "1", "RT_GRID": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_hierarchy_scan_knobs_give_the_same_bits(hip, scenes_mod, monkeypatch, env):
     """grid10k (10,004 spheres: the cell-grid scan by default): the bounds hierarchy instead (RT_GRID=0: 2,504 groups, four levels of
