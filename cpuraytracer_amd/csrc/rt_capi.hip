@@ -105,6 +105,8 @@ struct rt_ctx {
     bool useShadowGrid = true;  // RT_SHADOW_GRID=0 keeps every shadow ray on the scan
     DevBuf<float> radius;
     DevBuf<rt_material> mats;
+    DevBuf<uint4> mats16;     // the same table packed into 16 bytes per entry (rt_shade.h load_material16), when the scene allows it
+    bool mats16Ok = false;
     rtd::TraceParams base{};  // scene part filled at upload
 
     // accumulation state
@@ -853,6 +855,12 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     tp.fd_w = rtd::make_fastdiv(tp.W ? tp.W : 1u);
     tp.fd_rows = rtd::make_fastdiv(tp.rs.block_rows ? tp.rs.block_rows : 1u);
     tp.mats_in_lds = ctx->matsInLds ? 1u : 0u;
+    // packed materials (decided below, once it is known where the variant reads its materials from).  RT_MATS16: 0 never, 1 (default)
+    // from global memory wherever the 48-byte table would be read from there, 2 also staged into LDS by the flat stash variant.
+    // Measured (C2, three interleaved rounds): 48-byte records through L2 9,983 / packed from global memory 9,972 / packed in LDS
+    // with a 56-record stash 9,977 Msamples/s -- the material read is not what a hit waits for; C5: 7,579 -> 7,596.
+    const bool want16 = tp.mats16 != nullptr && EnvU32("RT_MATS16", 1u) != 0u;
+    tp.mats16_mode = 0u;
     tp.sg_glob16 = tp.sg_enabled ? rtd::sg_glob_slots(tp.sg_nglobal) : 0u;
     const size_t lds = LdsBytesFor(tp.n, tp.n_padded, ctx->matsInLds);
     if (tp.n_padded >= 65536) return Fail(RT_ERR_INVALID_ARG, "scenes beyond 65,000 spheres are not supported by the 16-bit candidate lists");
@@ -953,6 +961,14 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
                 matsL2 = true;
                 ldsBytes -= matBytes;
                 cap = cap2;
+                // ... and, RT_MATS16=2, their packed form into the room that leaves, when the stash keeps at least 48 records with it
+                const size_t m16Bytes = (size_t)tp.n_padded * 16;
+                const uint32_t cap3 = capFor(ldsBytes + m16Bytes);
+                if (want16 && EnvU32("RT_MATS16", 1u) >= 2u && cap3 >= 48u) {
+                    tp.mats16_mode = 2u;
+                    ldsBytes += m16Bytes;
+                    cap = cap3;
+                }
             }
         }
         if (stashKernel && cap >= 16u) {
@@ -965,6 +981,10 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
             ldsBytes += (size_t)wavesPerBlock * tp.ray_cache_stride16 * 16;
         }
         if (matsL2 && !useStash) return Fail(RT_ERR_HIP, "internal: materials through L2 without the stash variant");
+        // every other variant that reads its materials from GLOBAL memory takes the packed record from there (one 16-byte read per
+        // hit instead of three); variants with the 48-byte table in LDS keep it
+        const bool matsGlobal = matsL2 || tree || (grid && !gridLds) || !tp.mats_in_lds || (!flat && !ldsTables && !gridLds);
+        if (want16 && tp.mats16_mode == 0u && matsGlobal) tp.mats16_mode = 1u;
     }
     if (!useStash && ctx->useRayCache && ldsBytes + (size_t)wavesPerBlock * rtd::kRayCacheBytes <= 160 * 1024 / ctx->blocksPerCu) {
         tp.ray_cache_off16 = (uint32_t)(ldsBytes / 16);
@@ -1348,6 +1368,7 @@ void rt_destroy(rt_ctx* ctx) {
     ctx->lightRecs.Release();
     ctx->radius.Release();
     ctx->mats.Release();
+    ctx->mats16.Release();
     ctx->hdr.Release();
     ctx->ldr.Release();
     ctx->samples.Release();
@@ -1397,6 +1418,36 @@ int rt_set_workspace_limit(rt_ctx* ctx, uint64_t bytes) {
     return RT_OK;
 }
 
+// The material table packed into 16 bytes per scan entry (rt_shade.h load_material16), or false when some material of the scene
+// does not fit the form: a colour that is read (not a glass sphere's; rgb1 only under a checker texture) must be byte * (1 / 255)
+// exactly -- what XMLoadColor of an XMCOLOR gives, i.e. every colour the reference can hold (texture.cpp:5,16-17).
+static bool PackMaterials(const std::vector<rt_material>& matc, std::vector<uint4>& out) {
+    auto byteOf = [](float c, uint32_t& b) {
+        const float r = std::nearbyint(c * 255.0f);
+        if (!(r >= 0.f && r <= 255.f)) return false;
+        b = (uint32_t)r;
+        return (float)b * (1.0f / 255.0f) == c;
+    };
+    out.assign(matc.size(), make_uint4(0u, 0u, 0u, 0u));
+    for (size_t e = 0; e < matc.size(); ++e) {
+        const rt_material& m = matc[e];
+        if (m.type > 3u || m.tex_type > 1u) return false;
+        uint32_t c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
+        const bool glass = m.type == RT_MAT_DIELECTRIC_TRANSPARENT;
+        for (int k = 0; k < 3; ++k) {
+            if (!glass && !byteOf(m.rgb0[k], c0[k])) return false;
+            if (!glass && m.tex_type == RT_TEX_CHECKER && !byteOf(m.rgb1[k], c1[k])) return false;
+        }
+        const float slotA = m.type == RT_MAT_EMISSIVE ? m.luminance : m.smoothness;
+        const float slotB = glass ? m.ior : m.tiling;
+        uint32_t a, b;
+        std::memcpy(&a, &slotA, 4);
+        std::memcpy(&b, &slotB, 4);
+        out[e] = make_uint4(m.type | m.tex_type << 2 | c0[0] << 8 | c0[1] << 16 | c0[2] << 24, c1[0] | c1[1] << 8 | c1[2] << 16, a, b);
+    }
+    return true;
+}
+
 int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* materials, uint32_t n, const rt_camera* camera,
                     const rt_light* lights, uint32_t n_lights, const rt_material* sky, float exposure_scale) {
     if (!ctx || !spheres || !materials || !camera || (!lights && n_lights != 0) || !sky || n == 0)
@@ -1436,6 +1487,14 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     RT_HIP(hipMemcpy(ctx->leaf.ptr, L.leaf.data(), nPad * sizeof(float4), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->radius.ptr, rad.data(), nPad * sizeof(float), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->mats.ptr, matc.data(), nPad * sizeof(rt_material), hipMemcpyHostToDevice));
+    {
+        std::vector<uint4> m16;
+        ctx->mats16Ok = PackMaterials(matc, m16);
+        if (ctx->mats16Ok) {
+            if ((rc = ctx->mats16.Reserve(nPad)) != RT_OK) return rc;
+            RT_HIP(hipMemcpy(ctx->mats16.ptr, m16.data(), nPad * sizeof(uint4), hipMemcpyHostToDevice));
+        }
+    }
     {   // material type by ORIGINAL sphere index: what rt_tile_order_kernel classifies the pilot rays' first hits by
         std::vector<uint32_t> types(n);
         for (uint32_t k = 0; k < n; ++k) types[k] = materials[k].type;
@@ -1562,6 +1621,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_sphere* spheres, const rt_material* ma
     b.single_mask[1] = std::getenv("RT_SINGLE_DIRECT") && std::atoi(std::getenv("RT_SINGLE_DIRECT")) == 0 ? 0ull : L.singleMask[1];
     b.radius = ctx->radius.ptr;
     b.mats = ctx->mats.ptr;
+    b.mats16 = ctx->mats16Ok ? ctx->mats16.ptr : nullptr;
     b.n = n;
     b.n_padded = nPad;
     for (int k = 0; k < 3; ++k) {

@@ -96,6 +96,7 @@ struct SceneTabs {
     const float4* leaf;
     const float* rad;
     const rt_material* mats;
+    const uint4* mats16;    // packed materials in LDS (kMatsL2 variants with p.mats16_mode == 2), else null
     const float* ops;       // filter operand image of the top level (matrix-core scans)
     const float4* tree;
     const uint16_t *sgCell, *sgEntries, *sgGlobal;
@@ -125,6 +126,7 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
     T.leaf = p.leaf;
     T.rad = p.radius;
     T.mats = p.mats;
+    T.mats16 = nullptr;
     T.ops = nullptr;
     T.tree = p.tree;
     T.sgCell = p.sg_cell_start;
@@ -144,7 +146,9 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
         uint32_t* ldsOrig = reinterpret_cast<uint32_t*>(ldsLeaf + (kLeafLds ? (p.n_padded / 4u) * kLeafStride : 0u));
         float4* ldsMat = reinterpret_cast<float4*>(ldsOrig + p.n_padded);  // n_padded is a multiple of 4
         const uint32_t nMatLds = kMatsL2 ? 0u : ((kHitLds || p.mats_in_lds) ? p.n_padded : 0u);
-        float* ldsRad = reinterpret_cast<float*>(ldsMat + (size_t)nMatLds * 3);
+        // (kMatsL2: the 48-byte table stays in global memory; its 16-byte packed form takes the place when the launch says so)
+        const uint32_t nMat16 = (kMatsL2 && p.mats16_mode == 2u) ? p.n_padded : 0u;
+        float* ldsRad = reinterpret_cast<float*>(ldsMat + (size_t)nMatLds * 3 + nMat16);
         const float4* gMat = reinterpret_cast<const float4*>(p.mats);
         for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) {
             ldsScan[k] = p.scan[k];
@@ -152,6 +156,11 @@ RT_DEV void stage_scene(const TraceParams& p, float4* tabBase, SceneTabs& T) {
             if (kLeafLds) ldsLeaf[(k >> 2) * kLeafStride + (k & 3u)] = p.leaf[k];
         }
         for (uint32_t k = threadIdx.x; k < nMatLds * 3; k += blockDim.x) ldsMat[k] = gMat[k];
+        if (kMatsL2) {
+            const float4* g16 = reinterpret_cast<const float4*>(p.mats16);
+            for (uint32_t k = threadIdx.x; k < nMat16; k += blockDim.x) ldsMat[k] = g16[k];
+            T.mats16 = reinterpret_cast<const uint4*>(ldsMat);
+        }
         for (uint32_t k = threadIdx.x; k < p.n_padded; k += blockDim.x) ldsRad[k] = p.radius[k];
         if (kScan == 3) {
             // cell-grid scan with every table in LDS (kHitLds by construction): the cells' first entries, then the shadow index
@@ -356,6 +365,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& p) {
     const float4* leafTab = T.leaf;
     const float* radTab = T.rad;
     const rt_material* matTab = T.mats;
+    const uint4* mat16Lds = T.mats16;
     const float* mfmaOps = T.ops;
     const float4* treeTab = T.tree;
     const uint16_t* sgCell = T.sgCell;
@@ -495,7 +505,9 @@ __device__ __forceinline__ void trace_body(const TraceParams& p) {
         RT_SITE(H_PROCESS);
         const float4 S = scanTab[idx];
         const float radius = radTab[idx];  // radius and material tables are in scan-entry (clustered) order
-        const Mat m = load_material(matTab, idx);
+        // the packed 16-byte record where the launch provides it: from LDS (kMatsL2 variants, mode 2) or from global memory (mode 1)
+        const Mat m = (kMatsL2 && p.mats16_mode == 2u) ? load_material16(mat16Lds, idx)
+                                                        : (p.mats16_mode == 1u ? load_material16(p.mats16, idx) : load_material(matTab, idx));
         const V3 center = v3(S.x, S.y, S.z);
         const V3 nrm = div3(pos - center, radius);  // ray-tracing.cpp:58 (true divide; radius > 0)
         V3 atten, local, localOcc, tex;

@@ -133,6 +133,11 @@ struct TraceParams {
     uint32_t tree_in_lds;      // tree mode: stage every level of bounds into LDS (else the descent reads them through L2)
     const float* radius;       // [n_padded] per scan entry (clustered order)
     const rt_material* mats;   // [n_padded] per scan entry: material i of the reference belongs to sphere i = orig[entry]
+    // ... and the same table PACKED into 16 bytes per entry (rt_shade.h load_material16) when every material of the scene can be
+    // (colours are 8-bit by construction: XMLoadColor of an XMCOLOR): one 16-byte read per hit instead of three, and small enough
+    // for LDS next to a full hit stash.  mats16_mode: 0 = not used, 1 = read from global memory, 2 = staged into LDS (kMatsL2 variants)
+    const uint4* mats16;
+    uint32_t mats16_mode;
     uint32_t n;                // real spheres
     uint32_t n_groups;         // groups of four entries (even)
     uint32_t mats_in_lds;      // stage the material table into LDS (else it is read through L2)

@@ -24,6 +24,24 @@ RT_DEV Mat load_material(const rt_material* tab, int idx) {
     m.rgb1[0] = c.x; m.rgb1[1] = c.y; m.rgb1[2] = c.z; m.luminance = c.w;
     return m;
 }
+// The packed record (rt_capi.hip PackMaterials): w0 = type | tex_type << 2 | rgb0 bytes << 8, w1 = rgb1 bytes, w2 = smoothness (the
+// luminance of an Emissive, whose smoothness nobody reads), w3 = the ior of a DielectricTransparent, else the tiling (a glass
+// sphere has no texture).  A colour is byte * (1 / 255) in binary32: XMLoadColor as the path's contract restates it, the same
+// product the host formed -- the upload packs a scene only when every colour it holds IS such a product.
+RT_DEV Mat load_material16(const uint4* tab, int idx) {
+    const uint4 q = tab[idx];
+    const float k = 1.0f / 255.0f;
+    Mat m;
+    m.type = q.x & 3u;
+    m.tex_type = (q.x >> 2) & 1u;
+    m.smoothness = __uint_as_float(q.z);
+    m.luminance = __uint_as_float(q.z);
+    m.ior = __uint_as_float(q.w);
+    m.tiling = __uint_as_float(q.w);
+    m.rgb0[0] = (float)((q.x >> 8) & 255u) * k; m.rgb0[1] = (float)((q.x >> 16) & 255u) * k; m.rgb0[2] = (float)(q.x >> 24) * k;
+    m.rgb1[0] = (float)(q.y & 255u) * k; m.rgb1[1] = (float)((q.y >> 8) & 255u) * k; m.rgb1[2] = (float)((q.y >> 16) & 255u) * k;
+    return m;
+}
 RT_DEV V3 eval_texture(const Mat& m, float u, float v) {
     if (m.tex_type == RT_TEX_CHECKER) {  // texture.cpp:20-33
         const int iu = (int)(m.tiling * u);

@@ -939,6 +939,36 @@ def test_one_light_as_a_list_is_the_single_light_scene(hip, scenes_mod):
     del sc.lights
 
 
+@pytest.mark.parametrize("name,W,H", [("cover", 160, 100), ("grid10k", 112, 80)])
+def test_colours_that_are_not_bytes_take_the_unpacked_material_records(hip, oracle, scenes_mod, monkeypatch, name, W, H):
+    """The packed 16-byte material record (rt_shade.h load_material16) holds colours as bytes -- every colour the reference can hold
+    (XMLoadColor of an XMCOLOR; the oracle, like the reference, stores its textures as XMCOLOR, so colours off that grid are outside
+    the parity contract).  The ABI takes floats all the same: a scene with colours that are NOT byte * (1 / 255) must not be packed
+    (packing would snap them) -- it renders the same bits as under RT_MATS16=0, and other bits than its snapped twin; the snapped
+    scene (packed by default) equals the oracle."""
+    sc = scenes_mod.build_scene(name, 1, W, H)
+    imgs = []
+    for delta in (np.float32(3.1e-4), np.float32(0.0)):
+        m = sc.materials.copy()
+        m["rgb0"][::3] = np.clip(m["rgb0"][::3] + delta, 0, 1)
+        m["rgb1"][::5] = np.clip(m["rgb1"][::5] + delta, 0, 1)
+        sc2 = type(sc)(sc.spheres, m, sc.camera, sc.sun, sc.sky, sc.exposure_scale, sc.name, sc.seed)
+        hip.upload(sc2)
+        sg = hip.render(W, H, 1, 4, 50, 2)
+        hg = hip.download(ldr=False)[0]
+        s48, h48, _ = _render_with_env(monkeypatch, {"RT_MATS16": "0"}, sc2, W, H, 4, seed=2)
+        assert_same(hg, h48, "%s, colour offset %g: default vs the 48-byte records" % (name, delta))
+        assert (sg.traversals, sg.segments) == (s48.traversals, s48.segments)
+        imgs.append(hg)
+        if delta == 0.0:
+            orc = oracle.Oracle()
+            orc.upload(sc2)
+            so = orc.render(W, H, 1, 4, 50, 2, threads=8)
+            assert_same(hg, orc.download()[0], "%s, byte colours vs the oracle" % name)
+            assert (sg.traversals, sg.segments) == (so.traversals, so.segments)
+    assert not np.array_equal(imgs[0], imgs[1])
+
+
 def test_pipelining_falls_back_where_the_variant_does_not_apply(hip, scenes_mod):
     """grid10k runs the hierarchy scan, which has no carrying variant: the same calls run unpipelined and stay exact."""
     sc = scenes_mod.build_scene("grid10k", 1, 96, 96)
@@ -1107,6 +1137,9 @@ def _render_with_env(monkeypatch, env, sc, W, H, s1, depth=50, seed=1):
     {"RT_GRID": "2"},                                          # the cell-grid scan (tables in LDS) instead of the matrix-core filter
     {"RT_GRID": "2", "RT_MATS_LDS": "0"},                      # ... with its tables through L2
     {"RT_GRID": "2", "RT_STASH": "0", "RT_SHADOW_GRID": "0"},
+    {"RT_MATS16": "0"},                                        # the 48-byte material records through L2 instead of the packed 16-byte ones
+    {"RT_MATS16": "2"},                                        # the packed records staged into LDS (56-record stash)
+    {"RT_MATS16": "1", "RT_MATS_LDS": "0", "RT_STASH": "0"},
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_launch_and_layout_knobs_give_the_same_bits(hip, scenes_mod, monkeypatch, env):
     W, H, s1 = 161, 103, 5  # ragged: the last tile of the sample buffer is 9 pixels wide
@@ -1128,7 +1161,7 @@ def test_launch_and_layout_knobs_give_the_same_bits(hip, scenes_mod, monkeypatch
                                  {"RT_GRID": "0"}, {"RT_GRID": "0", "RT_TREE_LDS": "0", "RT_STASH": "0"}, {"RT_GRID": "0", "RT_BLOCK_THREADS": "512"},
                                  {"RT_STASH": "0"}, {"RT_STASH": "0", "RT_RAY_CACHE": "0"}, {"RT_BLOCK_THREADS": "256", "RT_BLOCKS_PER_CU": "2"},
                                  {"RT_STASH_CAP": "17"}, {"RT_GRID_SG_LDS": "1"}, {"RT_GRID_QUANT": "1"}, {"RT_GRID_QUANT": "1", "RT_STASH_CAP": "24"},
-                                 {"RT_SHADOW_CELLS": "64"}, {"RT_SHADOW_CELLS": "128", "RT_GRID": "0"}, {"RT_SG_SPH": "1"}, {"RT_SG_SPH": "1", "RT_GRID": "0"}],
+                                 {"RT_SHADOW_CELLS": "64"}, {"RT_SHADOW_CELLS": "128", "RT_GRID": "0"}, {"RT_SG_SPH": "1"}, {"RT_SG_SPH": "1", "RT_GRID": "0"}, {"RT_MATS16": "0"}, {"RT_MATS16": "0", "RT_GRID": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_hierarchy_scan_knobs_give_the_same_bits(hip, scenes_mod, monkeypatch, env):
     """grid10k (10,004 spheres: the cell-grid scan by default): the bounds hierarchy instead (RT_GRID=0: 2,504 groups, four levels of

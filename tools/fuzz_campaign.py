@@ -18,6 +18,10 @@ for seed in range(first, first + count):
     scale = float(rng.choice([1.0, 1.0, 1.0, 0.01, 30.0]))
     off = rng.choice([0.0, 0.0, 0.0, 50.0, 2000.0]) * rng.uniform(-1, 1, 3)
     sc, _ = T._fuzz_scene(oracle, seed, n, scale, tuple(off))
+    nl = int(os.environ.get("FUZZ_LIGHTS", "0"))  # > 0: the scene gets a LIST of 1 + (0..nl) lights (one may point below the horizon)
+    if nl:
+        extra = int(rng.integers(0, nl + 1))
+        sc.lights = [sc.sun] + [oracle.make_light(rng.normal(size=3) + [0, 0.4, 0], rng.uniform(0, 1, 3), float(rng.uniform(2000, 40000))) for _ in range(extra)]
     W, H, spp, depth = int(rng.choice([257, 320, 403])), int(rng.choice([160, 203])), int(rng.choice([1, 2, 3])), int(rng.choice([4, 20, 50]))
     r.upload(sc); orc.upload(sc)
     sg = r.render(W, H, 1, 1 + spp, depth, 9 + seed); hg, _ = r.download(ldr=False)
