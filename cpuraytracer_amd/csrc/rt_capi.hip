@@ -808,7 +808,7 @@ static TraceVariant ChooseVariant(const rt_ctx* ctx, const rtd::TraceParams& tp)
     V.tree = ctx->useMfma && !V.grid && tp.n_levels > 1;  // deeper hierarchy: tables stay in global memory (L2)
     const uint32_t topCnt = tp.level_cnt[tp.n_levels - 1];
     // the scene constants' slot comes first in the image, then the per-wave regions
-    V.candBytes = rtd::kConstBytes + (size_t)wavesPerBlock * ((V.tree || V.grid) ? rtd::kWaveCandBytes : rtd::kWaveListBytes) +
+    V.candBytes = rtd::kConstBytes + (size_t)wavesPerBlock * (V.grid ? rtd::kWaveGridBytes : (V.tree ? rtd::kWaveCandBytes : rtd::kWaveListBytes)) +
                   (size_t)tp.sg_glob16 * 16;  // ... and the shadow index's global list in front of the tables (rt_params.h sg_glob_slots)
     // one-sphere bounds, staged next to the scan table: the flat scan's copy has kFlatLeafStride float4 per group (rt_scan.h), the grid's is dense
     V.leafBytes = (size_t)(tp.n_padded / 4u) * (V.grid ? 4u : rtd::kFlatLeafStride) * 16;
@@ -855,11 +855,12 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     tp.fd_w = rtd::make_fastdiv(tp.W ? tp.W : 1u);
     tp.fd_rows = rtd::make_fastdiv(tp.rs.block_rows ? tp.rs.block_rows : 1u);
     tp.mats_in_lds = ctx->matsInLds ? 1u : 0u;
-    // packed materials (decided below, once it is known where the variant reads its materials from).  RT_MATS16: 0 never, 1 (default)
+    // packed materials (decided below, once it is known where the variant reads its materials from).  RT_MATS16: 0 (default) never, 1
     // from global memory wherever the 48-byte table would be read from there, 2 also staged into LDS by the flat stash variant.
     // Measured (C2, three interleaved rounds): 48-byte records through L2 9,983 / packed from global memory 9,972 / packed in LDS
-    // with a 56-record stash 9,977 Msamples/s -- the material read is not what a hit waits for; C5: 7,579 -> 7,596.
-    const bool want16 = tp.mats16 != nullptr && EnvU32("RT_MATS16", 1u) != 0u;
+    // with a 56-record stash 9,977 Msamples/s -- the material read is not what a hit waits for; C5: 7,579 -> 7,596; the unpacking adds 62 lane-operations per
+    // sample (+1.3 % of the kernel's VALU instructions, tools/phase_budget.py): same time for more instructions, so it stays off.
+    const bool want16 = tp.mats16 != nullptr && EnvU32("RT_MATS16", 0u) != 0u;
     tp.mats16_mode = 0u;
     tp.sg_glob16 = tp.sg_enabled ? rtd::sg_glob_slots(tp.sg_nglobal) : 0u;
     const size_t lds = LdsBytesFor(tp.n, tp.n_padded, ctx->matsInLds);
@@ -905,7 +906,7 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     tp.grid_in_lds = gridBytes ? 1u : 0u;
     // ... and, RT_GRID_QUANT=1 (experiments; BASELINE configs[4]'s "LDS-tiled sphere list"): in the stash variant with global tables
     // the QUANTISED one-sphere bounds behind the cells (rt_scan.h GridQuant: the step loop then reads no global memory) when they
-    // leave room for a stash of at least 24 records.  Measured on grid10k (4096^2, spp 64): 40 KB of bounds leave 38 stash records
+    // leave room for a stash of at least 16 records.  Measured on grid10k (4096^2, spp 64): 40 KB of bounds leave 38 stash records
     // instead of 63; 7.59 -> 7.10 Gsamples/s, of which -3.8 % is the smaller stash (float4 bounds at 38 records: 7.31) and -2.8 %
     // the 17 extra operations per tested sphere that unpack the record -- the float4 bounds hit L1 95 % of the time, and what the
     // L1 serves per cycle was not the limit it looked like (profiles/r04_c5_placement.json).  Default off.
@@ -913,7 +914,7 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
     if (grid && !gridLds && gridBytes != 0 && tp.grid_qrec != nullptr && ctx->useStash && carryMode == 0 && ctx->blockThreads == 1024 &&
         tp.max_depth < 65536u && EnvU32("RT_GRID_QUANT", 0u) != 0u && EnvU32("RT_GRID_SG_LDS", 0u) == 0u && EnvU32("RT_STASH_CAP", 63u) >= 16u) {
         const size_t qb = ((size_t)tp.n_padded * 4 + 15) / 16 * 16;
-        if (candBytes + gridBytes + qb + (size_t)wavesPerBlock * 24 * rtd::kStashDwords * 4 + 256 <= 160 * 1024) gridQBytes = qb;
+        if (candBytes + gridBytes + qb + (size_t)wavesPerBlock * 16 * rtd::kStashDwords * 4 + 256 <= 160 * 1024) gridQBytes = qb;
     }
     // cell-grid scan with its tables in global memory, RT_GRID_SG_LDS=1 (experiments): the shadow index in LDS next to the cells when
     // that leaves a stash of at least 24 records.  Measured on grid10k: 48.6 KB of index leave 31 records instead of 63: -5 %
@@ -964,7 +965,7 @@ static int LaunchTrace(rt_ctx* ctx, rtd::TraceParams& tp, int carryMode = 0) {
                 // ... and, RT_MATS16=2, their packed form into the room that leaves, when the stash keeps at least 48 records with it
                 const size_t m16Bytes = (size_t)tp.n_padded * 16;
                 const uint32_t cap3 = capFor(ldsBytes + m16Bytes);
-                if (want16 && EnvU32("RT_MATS16", 1u) >= 2u && cap3 >= 48u) {
+                if (want16 && EnvU32("RT_MATS16", 0u) >= 2u && cap3 >= 48u) {
                     tp.mats16_mode = 2u;
                     ldsBytes += m16Bytes;
                     cap = cap3;
@@ -1075,7 +1076,7 @@ static int LaunchClosest(rt_ctx* ctx, const float* dRays, uint32_t n, float* dOu
         tp.sg_in_lds = 0;
         const uint32_t topCnt = tp.level_cnt[tp.n_levels - 1];
         const size_t waves = 256 / 64;
-        size_t ldsBytes = waves * ((V.tree || V.grid) ? rtd::kWaveCandBytes : rtd::kWaveListBytes);
+        size_t ldsBytes = waves * (V.grid ? rtd::kWaveGridBytes : (V.tree ? rtd::kWaveCandBytes : rtd::kWaveListBytes));
         if (V.grid) {
             tp.grid_in_lds = 0;
         } else if (V.tree) {
@@ -2027,7 +2028,7 @@ int rt_unit_halton(rt_ctx* ctx, const uint32_t* index, uint32_t base, uint32_t n
 }
 
 int rt_unit_math(rt_ctx* ctx, uint32_t op, const float* x, const float* y, uint32_t n, float* out) {
-    if (!ctx || !x || !out || op > 6) return Fail(RT_ERR_INVALID_ARG, "rt_unit_math: invalid argument");
+    if (!ctx || !x || !out || op > 9) return Fail(RT_ERR_INVALID_ARG, "rt_unit_math: invalid argument");
     if (n == 0) return RT_OK;
     RT_HIP(hipSetDevice(ctx->device));
     TmpDev<float> dX, dY, dOut;

@@ -79,6 +79,35 @@ RT_DEV bool div_exponents_ok(float x0, float x1, float x2, float b) {
 #define RT_MARKSTEIN 0
 #endif
 
+// ---------------------------------------------------------------- correctly rounded square root, cheaper
+// sqrtf as the compiler expands it (scale test, v_sqrt_f32, the two neighbours with an fma residual each, two compare-and-select
+// pairs with their VCC wait states, unscale, class test) is 16 VALU operations and 4 s_nop.  Markstein's correction again: with
+// s0 = v_sqrt_f32(x) (1 ulp) and h = 0.5 v_rsq_f32(x) (1 ulp), the residual d = x - s0^2 is exact in an fma and
+// RN(s0 + d h) = RN(sqrt x): four operations behind the two hardware instructions.  Valid for x in [2^-80, inf) -- normal, away
+// from the flush of the two instructions; tests/test_gpu_parity.py::test_fast_square_root_is_ieee_square_root runs it on the
+// device for EVERY float of that range (1.74e9 patterns) against the IEEE root.  Anything else (zero, tiny, negative, inf, NaN
+// in ANY active lane of the wave: one uniform branch, not taken in practice) takes the compiler's sequence for the whole wave.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_NO_FAST_SQRT)
+#define RT_FAST_SQRT 1
+RT_DEV float sqrt_rn_core(float x) {
+    const float s0 = __builtin_amdgcn_sqrtf(x);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(x);
+    const float d = __builtin_fmaf(-s0, s0, x);
+    return __builtin_fmaf(d, h, s0);
+}
+RT_DEV bool sqrt_fast_range(float x) { return (__float_as_uint(x) - 0x17800000u) < 0x68000000u; }  // 2^-80 <= x < inf
+RT_DEV float sqrt_rn(float x) {
+    if (__builtin_expect(__ballot(!sqrt_fast_range(x)) == 0ull, 1)) return sqrt_rn_core(x);
+    {
+        RT_SITE(M_SQRT_SLOW);
+        return __builtin_sqrtf(x);
+    }
+}
+#else
+#define RT_FAST_SQRT 0
+RT_DEV float sqrt_rn(float x) { return __builtin_sqrtf(x); }
+#endif
+
 // v / b per component (true divide), b > 0.
 RT_DEV V3 div3(V3 v, float b) {
 #if RT_MARKSTEIN
@@ -96,7 +125,7 @@ RT_DEV V3 div3(V3 v, float b) {
 // XMVector3Normalize (SSE2): zero length -> 0, infinite length -> QNaN, else true divide.
 RT_DEV V3 normalize3(V3 v) {
     const float lenSq = dot3(v, v);
-    const float len = __builtin_sqrtf(lenSq);
+    const float len = sqrt_rn(lenSq);
     if (lenSq == __builtin_inff()) {
         const float q = __builtin_nanf("");
         return {q, q, q};
@@ -124,7 +153,7 @@ RT_DEV V3 refract3(V3 I, V3 N, float e) {
     k = k * e;
     k = 1.f - k;
     if (k <= 0.f) return {0.f, 0.f, 0.f};
-    float r = __builtin_sqrtf(k);
+    float r = sqrt_rn(k);
     r = r + e * d;
     return {e * I.x - r * N.x, e * I.y - r * N.y, e * I.z - r * N.z};
 }
@@ -136,7 +165,7 @@ RT_DEV float fresnel_term(float c, float n) {
     g = g - 1.f;
     t = t + g;
     g = __builtin_fabsf(t);
-    g = __builtin_sqrtf(g);
+    g = sqrt_rn(g);
     float gAddC = g + c;
     float gSubC = g - c;
     float res = gSubC * gSubC;

@@ -347,7 +347,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& p) {
     const MathTabs mt{ldsMath, ldsMath + 94, ldsMath + 127};
 #endif
     uint16_t* candBase = reinterpret_cast<uint16_t*>(smem + kConstBytes / 16);
-    constexpr uint32_t kWaveRegion = kScan >= 2 ? kWaveCandBytes : kWaveListBytes;  // the work lists of the hierarchy and grid scans
+    constexpr uint32_t kWaveRegion = wave_region_bytes<kScan>();  // the work lists of the flat, hierarchy or grid scan
     // the shadow index's global list (rt_params.h sg_glob_slots): spheres, then ids, in front of the tables
     float4* globSph = smem + kConstBytes / 16 + (kThreads / kWaveSize) * (kWaveRegion / 16);
     uint16_t* globIds = reinterpret_cast<uint16_t*>(globSph + p.sg_nglobal);
@@ -1232,6 +1232,13 @@ __global__ void k_unit_math(uint32_t op, const float* x, const float* y, uint32_
     else if (op == 5) r = x[k] / y[k];
 #endif
     else if (op == 6) r = x[k] / y[k];      // the compiler's IEEE division, on the device
+    else if (op == 7) r = sqrt_rn(x[k]);    // the square root the path takes (guarded): must equal the IEEE root for every x
+#if RT_FAST_SQRT
+    else if (op == 8) r = sqrt_rn_core(x[k]);  // ... its fast form alone: the IEEE root for x in [2^-80, inf)
+#else
+    else if (op == 8) r = __builtin_sqrtf(x[k]);
+#endif
+    else if (op == 9) r = __builtin_sqrtf(x[k]);  // the compiler's IEEE square root, on the device
     out[k] = r;
 }
 __global__ void k_unit_primary(const TraceParams p, const uint32_t* ijs, uint32_t n, float* out) {
@@ -1248,7 +1255,7 @@ __global__ void k_unit_primary(const TraceParams p, const uint32_t* ijs, uint32_
 template <bool kLds, int kScan>
 __global__ void __launch_bounds__(256) k_unit_closest(const TraceParams p, const float* rays, uint32_t n, float* out) {
     extern __shared__ float4 smem[];
-    constexpr uint32_t kWaveRegion = kScan >= 2 ? kWaveCandBytes : kWaveListBytes;
+    constexpr uint32_t kWaveRegion = wave_region_bytes<kScan>();
     uint16_t* candBase = reinterpret_cast<uint16_t*>(smem);
     float4* tabBase = smem + (256 / kWaveSize) * (kWaveRegion / 16);
     SceneTabs T;

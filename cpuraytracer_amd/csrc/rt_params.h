@@ -288,7 +288,7 @@ RT_DEV void camera_get_ray(const P& p, float uvx, float uvy, float lensx, float 
 RT_DEV void halton_disk_4_5(uint32_t k, float& lensx, float& lensy, uint32_t sampler = 0u) {  // quasi-random.cpp:52-61
     const float theta = (2.f * 3.141592654f) * halton(k, 4);
     float r = halton(k, 5);  // the reference does not take the square root: a centre-weighted disk
-    if (sampler & RT_SAMPLER_SQRT_DISK) r = __builtin_sqrtf(r);
+    if (sampler & RT_SAMPLER_SQRT_DISK) r = sqrt_rn(r);
     double sn, cs;
     sincos_f64(theta, sn, cs);
     lensx = r * (float)cs;

@@ -21,7 +21,7 @@ constexpr uint32_t kScanGroup = 4;
 // Reference-order root evaluation for entry i (ray-tracing.cpp:54-71); ties keep the lower ORIGINAL index.
 RT_DEV void root_test(float disc, float b, float a, uint32_t i, const uint32_t* __restrict__ orig, float& tmin, int& idx) {
     if (disc > 0.f) {  // ray-tracing.cpp:54
-        const float sq = __builtin_sqrtf(disc);
+        const float sq = sqrt_rn(disc);
         float t = (-b - sq) / a;                // :56
         if (!(t > 0.001f)) t = (-b + sq) / a;   // :58, :69-71 (bias 0.001, :52)
         if (t > 0.001f && (t < tmin || (t == tmin && idx >= 0 && orig[i] < orig[idx]))) {
@@ -113,7 +113,7 @@ RT_DEV void resolve_group(const float4* __restrict__ tab, const uint32_t* __rest
         m &= m - 1u;
         const float e = k == 0u ? e0 : (k == 1u ? e1 : (k == 2u ? e2 : e3));
         const float b = k == 0u ? b0 : (k == 1u ? b1 : (k == 2u ? b2 : b3));
-        const float sq = __builtin_sqrtf(e);
+        const float sq = sqrt_rn(e);
         float t = (-b - sq) / a;               // ray-tracing.cpp:56
         if (!(t > 0.001f)) t = (-b + sq) / a;  // :69
         const int cand = (int)(g + k);
@@ -205,6 +205,28 @@ static_assert(kPoolB > 4 * 64 && (kPoolA * 2 + kPoolB * 2) % 16 == 0, "a round m
 constexpr uint32_t kWaveListBytes = kPoolA * 2 + kPoolB * 2 + 64 * 8;      // item pools + per-ray best keys = 2816 B per wave
 static_assert(kTreeExact >= kFarDrain + 4 * 64, "a round may add 256 entries to an exact list that holds up to kFarDrain - 1");
 constexpr uint32_t kWaveCandBytes = kTreeWork * 4 + kTreeExact * 4 + 64 * 8;  // hierarchy scan: 5888 B per wave
+// Cell-grid scan: (ray, slab) items of up to RT_GRID_FEED slabs per ray and feed pass.  Measured on grid10k (4096^2, spp 64; the
+// list's bytes come out of the hit stash): 4 slabs / 320 items 8,205 Msamples/s, 6 / 384 8,175, 8 / 512 8,383, 8 / 640 8,474,
+// 10 / 640 8,448, 8 / 768 8,326, 12 / 768 8,413, 16 / 1024 8,210; 2 / 320 7,770.
+#ifndef RT_GRID_FEED
+#define RT_GRID_FEED 8
+#endif
+#ifndef RT_GRID_WORK
+#define RT_GRID_WORK 640
+#endif
+constexpr uint32_t kGridWork = RT_GRID_WORK;
+#ifndef RT_GRID_DRAIN
+#define RT_GRID_DRAIN 32
+#endif
+// exact entries that trigger a drain in the grid scan: the walk is front to back, so early hits end it early -- measured on
+// grid10k: 128 (the hierarchy's value) -> 64 +1.5 %, 48 +2.3 %, 32 +3.5 %; round 4 (no limits in the step loop): 16 / 24 / 32 / 64 /
+// 128: 8,193 / 8,208 / 8,228 / 8,068 / 7,956 Msamples/s
+constexpr uint32_t kGridDrain = RT_GRID_DRAIN;
+constexpr uint32_t kGridExact = kGridDrain + 4 * 64;  // a step may add 256 entries to an exact list that holds up to kGridDrain - 1
+constexpr uint32_t kWaveGridBytes = kGridWork * 4 + kGridExact * 4 + 64 * 8;  // grid scan: 4224 B per wave
+static_assert(kWaveGridBytes % 16 == 0 && ((kGridWork + kGridExact) * 4) % 8 == 0, "per-wave regions are float4 aligned, the keys behind the lists 8-byte aligned");
+template <int kScan>
+constexpr uint32_t wave_region_bytes() { return kScan == 3 ? kWaveGridBytes : (kScan == 2 ? kWaveCandBytes : kWaveListBytes); }
 // K of the filter margins (units of eps * a * G; the host folds the same K into each bound): the matrix-core level needs
 // 101*16 (exact-path rounding, amplified by the member offsets) + ~600 (split-bf16 operands); levels tested on the VALU
 // in f32 need 101*16 + 30; a one-sphere bound (offset 0) needs 16 + 30.
@@ -288,6 +310,46 @@ RT_DEV void build_mfma_operands(const float4* __restrict__ bounds, uint32_t nGro
     }
 }
 
+// Square roots of the FILTERS' thresholds (the "behind" threshold bt, the reach of a root's rounding): any value >= the true root
+// keeps a filter conservative, so the hardware's 1-ulp v_sqrt_f32, nudged up, stands in for the correctly rounded one (16
+// instructions).  Inputs below 1e-30 (which the instruction would flush) are raised to it: the result only grows.
+#ifndef RT_FILTER_SQRT_RAW
+#define RT_FILTER_SQRT_RAW 1
+#endif
+RT_DEV float filter_sqrt_up(float x) {
+#if RT_FILTER_SQRT_RAW && defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(__builtin_fmaxf(x, 1e-30f)) * 1.000001f;
+#else
+    return __builtin_sqrtf(x);
+#endif
+}
+
+// t of Sphere::Intersect for a pooled (ray, sphere) pair (ray-tracing.cpp:56, :69): the first root, or the second where the first
+// does not exceed the bias.  RT_EXACT_MARKSTEIN: the two IEEE quotients through Markstein's correction (rt_device_math.h) when
+// every lane's a is in [2^-19, 2^100] and its numerators are below 2^100: a quotient that is normal is then the IEEE quotient,
+// and one that is not (|t| < 2^-80) fails `t > 0.001` in either form and is never kept (rt_shade.h root_exceeds_bias argues the
+// same for the shadow rays).
+#ifndef RT_EXACT_MARKSTEIN
+#define RT_EXACT_MARKSTEIN 1
+#endif
+RT_DEV float pooled_root(float b, float sq, float ra) {
+#if RT_MARKSTEIN && RT_EXACT_MARKSTEIN
+    const bool ok = (__float_as_uint(ra) - 0x36000000u) <= 0x3b800000u && (__builtin_fabsf(b) + sq) < 0x1p100f;
+    if (__builtin_expect(__ballot(!ok) == 0ull, 1)) {
+        const float ya = recip_rn(ra);
+        float t = div_rn(-b - sq, ra, ya);
+        if (!(t > 0.001f)) t = div_rn(-b + sq, ra, ya);
+        return t;
+    }
+#endif
+    {
+        RT_SITE(M_ROOT_SLOW);
+        float t = (-b - sq) / ra;
+        if (!(t > 0.001f)) t = (-b + sq) / ra;
+        return t;
+    }
+}
+
 // min(x, p) for p > 0 as ONE integer instruction: a negative float's pattern is a negative integer (below every
 // positive one) and positive floats order like their patterns.  (fminf would add a canonicalising v_max per operand.)
 RT_DEV float min_with_positive(float x, float p) {
@@ -302,7 +364,22 @@ RT_DEV float min_with_positive(float x, float p) {
 // spheres, has t < 0 and the reference accepts no root (bias 0.001, ray-tracing.cpp:52).
 // All three conditions are sign bits: one 3-input bit operation forms "rejected", one v_alignbit appends its sign bit
 // to the lane's bitmap word (four VALU operations per (ray, group) pair, no branches, no LDS).
+#ifndef RT_PK_POST
+#define RT_PK_POST 0  // 1: the fma of two (ray, group) pairs as one v_pk_fma_f32 (half the issue slots of that third of the filter's arithmetic)
+#endif
 RT_DEV void mfma_post(const f32x16& Tb, const f32x16& Tg, float bthr, uint32_t& rejectedBits) {
+#if RT_PK_POST
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) {
+        const f32x2 m = {min_with_positive(Tb[e], bthr), min_with_positive(Tb[e + 1], bthr)};
+        const f32x2 b = {Tb[e], Tb[e + 1]};
+        const f32x2 t = {Tg[e], Tg[e + 1]};
+        const f32x2 g = __builtin_elementwise_fma(m, b, -t);
+        rejectedBits = __builtin_amdgcn_alignbit(rejectedBits, __float_as_uint(g[0]), 31);
+        rejectedBits = __builtin_amdgcn_alignbit(rejectedBits, __float_as_uint(g[1]), 31);
+    }
+    return;
+#endif
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const float t = Tg[e];  // a*cc~ - M: the per-ray constant is part of the contraction
@@ -418,7 +495,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
     const float oo = dot3(o, o);
     const float cr = live ? (a * oo) * (1.f - 2.f * kMarginRel) : 1e30f;
     const float crLeaf = (a * oo) * (1.f - 2.f * kMarginKLeaf * 5.9604645e-8f);  // ... and of the one-sphere bounds
-    const float bt = 1e-4f * __builtin_sqrtf(a) * (__builtin_sqrtf(oo) + boundNorm);
+    const float bt = 1e-4f * filter_sqrt_up(a) * (filter_sqrt_up(oo) + boundNorm);
     // ray-side operands: values (k = 0,1 | 2,3) of the b chain [dx, dy | dz, d.o] and of the a*cc chain [gx, gy | gz, a].
     // Tile 0 (rays of lanes 0-31) takes k = 0,1 from the owner and k = 2,3 from lane+32; tile 1 the other way round:
     // v_permlane32_swap exchanges exactly those halves (upper half of the first register <-> lower half of the second).
@@ -595,9 +672,8 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                 const float b = (ocx * rdx + ocy * rdy) + ocz * rdz;
                 const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;
                 const float e = b * b - ra * cc;
-                const float sq = __builtin_sqrtf(e);
-                float t = (-b - sq) / ra;               // ray-tracing.cpp:56
-                if (!(t > 0.001f)) t = (-b + sq) / ra;  // :69
+                const float sq = sqrt_rn(e > 0.f ? e : 1.f);  // (a root is read only where e > 0: the other lanes keep the wave on the fast path)
+                const float t = pooled_root(b, sq, ra);  // ray-tracing.cpp:56, :69
                 // `e > 0` is the reference's own test (ray-tracing.cpp:54); `t < inf` is the scan's initial tmin
                 if (has && e > 0.f && t > 0.001f && t < __builtin_inff()) {
                     RT_SITE(S_BMIN);
@@ -645,9 +721,8 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                 const float b = (ocx * rdx + ocy * rdy) + ocz * rdz;
                 const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;
                 const float e = b * b - ra * cc;
-                const float sq = __builtin_sqrtf(e);
-                float t = (-b - sq) / ra;               // ray-tracing.cpp:56
-                if (!(t > 0.001f)) t = (-b + sq) / ra;  // :69
+                const float sq = sqrt_rn(e > 0.f ? e : 1.f);  // (a root is read only where e > 0: the other lanes keep the wave on the fast path)
+                const float t = pooled_root(b, sq, ra);  // ray-tracing.cpp:56, :69
                 // `e > 0` is the reference's own test (ray-tracing.cpp:54); `t < inf` is the scan's initial tmin
                 if (has && e > 0.f && t > 0.001f && t < __builtin_inff()) {
                     RT_SITE(S_BMIN);
@@ -828,7 +903,7 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
             // (r + delta)^2 <= r^2 + E''/a: delta <= min(sqrt(X), X / (2 r_min)), X = 32 eps (2|o|^2 + 3 A^2) (twice E for the root's
             // own square root and division)
             const float X = 32.f * 5.9604645e-8f * __builtin_fmaf(2.f, oo, treeBox[7]);
-            const float reach = __builtin_fminf(__builtin_sqrtf(X), X * treeBox[8]);
+            const float reach = __builtin_fminf(filter_sqrt_up(X), X * treeBox[8]);
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
                 const float pad = reach + 1e-6f * (__builtin_fabsf(oc[ax]) + treeBox[6]);
@@ -863,9 +938,8 @@ RT_DEV void scan_list_mfma(const float4* __restrict__ tab, const float4* __restr
                 const float b = (ocx * rdx + ocy * rdy) + ocz * rdz;
                 const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;
                 const float e = b * b - ra * cc;
-                const float sq = __builtin_sqrtf(e);
-                float t = (-b - sq) / ra;               // ray-tracing.cpp:56
-                if (!(t > 0.001f)) t = (-b + sq) / ra;  // :69
+                const float sq = sqrt_rn(e > 0.f ? e : 1.f);  // (a root is read only where e > 0: the other lanes keep the wave on the fast path)
+                const float t = pooled_root(b, sq, ra);  // ray-tracing.cpp:56, :69
                 if (has && e > 0.f && t > 0.001f && t < __builtin_inff()) {
                     const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((orig[cand] << 16) | cand);
                     __hip_atomic_fetch_min(best + r, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1057,13 +1131,6 @@ RT_DEV float4 grid_quant_bound(uint32_t rec, float uBase, const GridQuant& Q) {
     const float w = __builtin_fmaf(c2, 1.f - 264.f * 5.9604645e-8f, __builtin_fmaf(R * R, -(1.f + 1e-5f + 320.f * 5.9604645e-8f), -Q.s2));
     return make_float4(cu, cv, cw, w);
 }
-#ifndef RT_GRID_DRAIN
-#define RT_GRID_DRAIN 32
-#endif
-// exact entries that trigger a drain in the grid scan: the walk is front to back, so early hits end it early -- measured on
-// grid10k: 128 (the hierarchy's value) -> 64 +1.5 %, 48 +2.3 %, 32 +3.5 %
-constexpr uint32_t kGridDrain = RT_GRID_DRAIN;
-static_assert(kTreeExact >= kGridDrain + 4 * 64, "a step may add 256 entries to an exact list that holds up to kGridDrain - 1");
 #ifndef RT_GRID_STEP
 #define RT_GRID_STEP 4
 #endif
@@ -1130,11 +1197,11 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
     const float duQ = G.axU == 0u ? d.x : (G.axU == 1u ? d.y : d.z), dvQ = G.axV == 0u ? d.x : (G.axV == 1u ? d.y : d.z), dwQ = axW == 0u ? d.x : (axW == 1u ? d.y : d.z);
     const float oo = dot3(o, o);
     const float aoo = a * oo;
-    const float bt = 1e-4f * __builtin_sqrtf(a) * (__builtin_sqrtf(oo) + boundNorm);
+    const float bt = 1e-4f * filter_sqrt_up(a) * (filter_sqrt_up(oo) + boundNorm);
     const float crLeaf = aoo * (1.f - 2.f * kMarginKLeaf * 5.9604645e-8f);
-    uint32_t* work = reinterpret_cast<uint32_t*>(waveCand);               // kTreeWork items: ray << 8 | slab
-    uint32_t* exact = work + kTreeWork;                                   // kTreeExact entries: ray << 16 | scan entry
-    unsigned long long* best = reinterpret_cast<unsigned long long*>(exact + kTreeExact);
+    uint32_t* work = reinterpret_cast<uint32_t*>(waveCand);               // kGridWork items: ray << 8 | slab
+    uint32_t* exact = work + kGridWork;                                   // kGridExact entries: ray << 16 | scan entry
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(exact + kGridExact);
     best[lane] = ~0ull;
     wave_lds_handoff();
     uint32_t nWork = 0, nExact = 0;
@@ -1145,7 +1212,7 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
     {
         const float oc[3] = {o.x, o.y, o.z}, dc[3] = {d.x, d.y, d.z};
         const float X = 32.f * 5.9604645e-8f * __builtin_fmaf(2.f, oo, treeBox[7]);
-        const float reach = __builtin_fminf(__builtin_sqrtf(X), X * treeBox[8]);
+        const float reach = __builtin_fminf(filter_sqrt_up(X), X * treeBox[8]);
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             const float pad = reach + 1e-6f * (__builtin_fabsf(oc[ax]) + treeBox[6]);
@@ -1198,9 +1265,8 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
             const float b = (ocx * rdx + ocy * rdy) + ocz * rdz;
             const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;
             const float e = b * b - ra * cc;
-            const float sq = __builtin_sqrtf(e);
-            float t = (-b - sq) / ra;               // ray-tracing.cpp:56
-            if (!(t > 0.001f)) t = (-b + sq) / ra;  // :69
+            const float sq = sqrt_rn(e > 0.f ? e : 1.f);  // (a root is read only where e > 0: the other lanes keep the wave on the fast path)
+            const float t = pooled_root(b, sq, ra);  // ray-tracing.cpp:56, :69
             if (has && e > 0.f && t > 0.001f && t < __builtin_inff()) {
                 RT_SITE(G_BMIN);
                 const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((og << 16) | cand);
@@ -1213,26 +1279,51 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
     // The big spheres (at most eight, entries 4q): the owner lane tests its own ray against the sphere's one-sphere bound --
     // the floor is hit by most rays, the others by few -- and the survivors take one exact slot each; their hits are the walk's
     // first far limits.
-    const float btBig = 1e-4f * __builtin_sqrtf(a) * (__builtin_sqrtf(oo) + G.bigNorm);
+    const float btBig = 1e-4f * filter_sqrt_up(a) * (filter_sqrt_up(oo) + G.bigNorm);
+#ifndef RT_BIG_BATCH
+#define RT_BIG_BATCH 1  // 1: the big spheres' bounds four at a time, ONE prefix sum and one push loop per four (0: a ballot and a push per sphere)
+#endif
+#if RT_BIG_BATCH
+    static_assert(kGridExact >= 4u * kWaveSize, "four big spheres per batch: 256 entries");
+    for (uint32_t q0 = 0; q0 < nAlways; q0 += 4u) {
+        uint32_t mb = 0u;  // bit k: the bound of big sphere q0 + k may hold a root of this lane's ray
+        const uint32_t qe = nAlways - q0 < 4u ? nAlways - q0 : 4u;
+        for (uint32_t k = 0; k < qe; ++k) {
+            RT_SITE(G_BIG);
+            const int rej = bound_rejected(leaf[4u * (q0 + k)], v3(gx, gy, gz), d, a, dO, crLeaf, btBig);
+            mb |= (rej >= 0 ? 1u : 0u) << k;
+        }
+        if (!live) mb = 0u;
+        const uint32_t nh = (uint32_t)__builtin_popcount(mb);
+        const uint32_t incl = wave_inclusive_sum(nh);
+        uint32_t* wp = exact + (incl - nh);  // (the list is empty here: every batch ends in a drain)
+        while (mb != 0u) {
+            RT_SITE(G_BIGPUSH);
+            const uint32_t k = (uint32_t)__builtin_ctz(mb);
+            mb &= mb - 1u;
+            *wp++ = lane << 16 | (4u * (q0 + k));
+        }
+        nExact = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (nExact != 0u) drainExact();
+    }
+#else
     for (uint32_t q = 0; q < nAlways; ++q) {
         RT_SITE(G_BIG);
-        if (nExact + (uint32_t)kWaveSize > kTreeExact) drainExact();
+        if (nExact + (uint32_t)kWaveSize > kGridExact) drainExact();
         const bool cand = live && bound_rejected(leaf[4u * q], v3(gx, gy, gz), d, a, dO, crLeaf, btBig) >= 0;
         const uint64_t lm = __ballot(cand);
         if (cand) exact[nExact + prefix_count(lm)] = lane << 16 | (4u * q);
         nExact += (uint32_t)__popcll(lm);
     }
     if (nExact != 0u) drainExact();
-    const int nv = (int)G.nv;
-#ifndef RT_GRID_FEED
-#define RT_GRID_FEED 4
 #endif
+    const int nv = (int)G.nv;
     constexpr uint32_t kFeed = RT_GRID_FEED;  // slabs a ray lists per feed pass (a pass adds at most 64 * kFeed items)
-    static_assert(kTreeWork >= 64u * kFeed, "one feed pass must fit the work list");
+    static_assert(kGridWork >= 64u * kFeed, "one feed pass must fit the work list");
     for (;;) {
         // feed: every ray with slabs left lists its next (up to) kFeed of them, front to back -- (ray, slab) is all an item says;
         // a ray whose next slab begins beyond its closest hit so far is done
-        while (nWork + 64u * kFeed <= kTreeWork && __ballot(pending) != 0ull) {
+        while (nWork + 64u * kFeed <= kGridWork && __ballot(pending) != 0ull) {
             RT_SITE(G_FEED);
             uint32_t cnt = 0;
             if (pending) {
@@ -1291,16 +1382,27 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
             // four spheres per step; every lane runs as many steps as the longest run of the round needs
             while (__ballot(eb < ee) != 0ull) {
                 RT_SITE(G_STEP);
+#ifndef RT_GRID_SPAN
+#define RT_GRID_SPAN 0  // limits in the step loop's bound test: 0 none (default: the limits cost more than the exact tests they save, +5.2 % on grid10k), 1 the far limit (the closest hit so far), 2 near and far
+#endif
+#if RT_GRID_SPAN
                 const uint32_t tbits = reinterpret_cast<const uint32_t*>(best + r)[1];  // far limit: the ray's closest hit so far
                 float fu = tbits < 0x7f800000u ? (fa * __uint_as_float(tbits)) * (1.f + 0x1p-10f) : __builtin_inff();
                 fu = __builtin_fminf(fu, fuf);
+#endif
                 uint32_t rb = 0u;
 #pragma unroll
                 for (uint32_t q = 0; q < kGridStep; ++q) {
                     const uint32_t e = eb + q;
                     // (entry 0 is always there; its result is masked)
                     const float4 B = kQ ? grid_quant_bound(Q.rec[e < ee ? e : 0u], uBaseQ, Q) : leaf[e < ee ? e : 0u];
+#if RT_GRID_SPAN == 2
                     const int rej = e < ee ? bound_rejected_span(B, fg, fd, fa, fdO, fcr, fbt, fun, fu) : -1;
+#elif RT_GRID_SPAN == 1
+                    const int rej = e < ee ? bound_rejected_far(B, fg, fd, fa, fdO, fcr, fbt, fu) : -1;
+#else
+                    const int rej = e < ee ? bound_rejected(B, fg, fd, fa, fdO, fcr, fbt) : -1;
+#endif
                     rb = __builtin_amdgcn_alignbit(rb, (uint32_t)rej, 31);
                 }
                 const uint32_t m = ~rb & ((1u << kGridStep) - 1u);  // bit kGridStep-1-q = entry eb + q
@@ -1310,7 +1412,7 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
                     const uint32_t nh = (uint32_t)__builtin_popcount(mask);
                     const uint32_t incl = wave_inclusive_sum(nh);
                     const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    if (kGridStep > 4u && nExact + tot > kTreeExact) drainExact();  // (four per step: the drain above keeps a step's room)
+                    if (kGridStep > 4u && nExact + tot > kGridExact) drainExact();  // (four per step: the drain above keeps a step's room)
                     uint32_t* wp = exact + nExact + (incl - nh);
                     uint32_t mm = mask;
                     while (mm != 0u) {
@@ -1321,7 +1423,7 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
                     }
                     nExact += tot;
                 };
-                if (kGridStep > 4u && (uint32_t)__popcll(__ballot(m != 0u)) * kGridStep > kTreeExact) {
+                if (kGridStep > 4u && (uint32_t)__popcll(__ballot(m != 0u)) * kGridStep > kGridExact) {
                     // (more survivors than the list holds are possible in principle: eight per lane; then the step is pushed in halves)
                     pushSurvivors(m & 0xf0u);
                     pushSurvivors(m & 0x0fu);

@@ -29,6 +29,7 @@ RT_DEV Mat load_material(const rt_material* tab, int idx) {
 // sphere has no texture).  A colour is byte * (1 / 255) in binary32: XMLoadColor as the path's contract restates it, the same
 // product the host formed -- the upload packs a scene only when every colour it holds IS such a product.
 RT_DEV Mat load_material16(const uint4* tab, int idx) {
+    RT_SITE(H_MAT16);
     const uint4 q = tab[idx];
     const float k = 1.0f / 255.0f;
     Mat m;
@@ -134,11 +135,11 @@ RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V
                 const float u2 = draws.next();
                 // quasi-random.cpp:41: uniform in solid angle (z = u1); the flagged variant is cosine weighted
                 const bool cosine = (sampler & RT_SAMPLER_COSINE_HEMISPHERE) != 0u;
-                const float r = __builtin_sqrtf(cosine ? u1 : 1.f - u1 * u1);
+                const float r = sqrt_rn(cosine ? u1 : 1.f - u1 * u1);
                 const float phi = (2.f * 3.141592654f) * u2;
                 double sn, cs;
                 sincos_f64(phi, sn, cs, mt);
-                const float hx = r * (float)cs, hy = r * (float)sn, hz = cosine ? __builtin_sqrtf(1.f - u1) : u1;
+                const float hx = r * (float)cs, hy = r * (float)sn, hz = cosine ? sqrt_rn(1.f - u1) : u1;
                 const V3 b3 = nrm;
                 const V3 up = __builtin_fabsf(nrm.x) < 0.5f ? v3(1.f, 0.f, 0.f) : v3(0.f, 1.f, 0.f);
                 const V3 b1 = cross3(up, b3);
@@ -148,7 +149,9 @@ RT_DEV bool scatter_only(const Mat& m, V3 rd, V3 nrm, Draws& draws, V3& atten, V
             scattered = true;
         }
     }
-    outDir = normalize3(raw);
+    // (a lane that does not scatter normalises a unit vector instead of zero: its result is discarded, and a zero length in ANY
+    // lane would send the whole wave through the slow square root -- a quarter of the waves of the cover scene hold such a lane)
+    outDir = normalize3(scattered ? raw : v3(1.f, 0.f, 0.f));
     if (!scattered) outDir = v3(0.f, 0.f, 0.f);
     return scattered;
 }
@@ -235,7 +238,7 @@ RT_DEV bool sphere_any_hit(const float4 S, V3 o, V3 d, float a, float ya, bool a
     const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - S.w;
     const float disc = b * b - a * cc;
     if (disc > 0.f) {  // ray-tracing.cpp:54-71
-        const float sq = __builtin_sqrtf(disc);
+        const float sq = sqrt_rn(disc);
         if (root_exceeds_bias(-b - sq, a, ya, aOk)) return true;
         if (root_exceeds_bias(-b + sq, a, ya, aOk)) return true;
     }

@@ -247,7 +247,9 @@ uint32_t rt_rowset_global_row(rt_rowset rs, uint32_t local_row);
 /* Random::HaltonSample — quasi-random.cpp:3-16 */
 int rt_unit_halton(rt_ctx* ctx, const uint32_t* index, uint32_t base, uint32_t n, float* out);
 /* op 0: sin, 1: cos, 2: pow(x,y), 3: tan — the shared elementary-function contract; 4: the refined reciprocal and
- * 5: the guarded Markstein quotient x/y of the hit processing (both must equal IEEE division); 6: plain x/y on the device */
+ * 5: the guarded Markstein quotient x/y of the hit processing (both must equal IEEE division); 6: plain x/y on the device;
+ * 7: the path's square root (guarded fast form), 8: its fast form alone (x in [2^-80, inf)), 9: the compiler's sqrtf on the
+ * device -- all three must equal the IEEE square root */
 int rt_unit_math(rt_ctx* ctx, uint32_t op, const float* x, const float* y, uint32_t n, float* out);
 /* GenerateRays for chosen pixels: (i,j,s) -> origin xyz, direction xyz (6 floats each) */
 int rt_unit_primary_rays(rt_ctx* ctx, uint32_t W, uint32_t H, const uint32_t* ijs /*3 per ray*/,

@@ -98,6 +98,33 @@ def test_markstein_division_is_ieee_division(hip):
         assert_same(hip.unit_math(5, xs, bb), (xs / bb).astype(np.float32), "quotients by significand %#x" % bits_)
 
 
+def test_fast_square_root_is_ieee_square_root(hip):
+    """The path's square root (rt_device_math.h sqrt_rn: v_sqrt_f32, v_rsq_f32 and Markstein's correction, four operations
+    instead of the compiler's sixteen) must be the IEEE root.  (a) the fast form alone on EVERY float of its range [2^-80, inf):
+    1.74e9 patterns against numpy's correctly rounded root; (b) the guarded form as the path calls it, and the compiler's own
+    sqrtf on the device, on every kind of input -- zeros, denormals, the range's edges, negatives, inf, NaN, mixed into waves
+    of ordinary values (one lane outside the fast range sends its whole wave through the compiler's sequence)."""
+    lo, hi, step = 0x17800000, 0x7f800000, 1 << 26
+    for base in range(lo, hi, step):
+        bits_ = np.arange(base, min(base + step, hi), dtype=np.uint32)
+        x = bits_.view(np.float32)
+        assert_same(hip.unit_math(8, x), np.sqrt(x), "fast square root, patterns from %#x" % base)
+    rng = np.random.default_rng(11)
+    x = rng.integers(0, 1 << 32, 8_000_000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    specials = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 1.1754942e-38, 1.17549435e-38, 8.27e-25, 8.2718061e-25, 3.4028235e38, -1.0],
+                        dtype=np.float32)
+    x[rng.integers(0, x.size, 200_000)] = specials[rng.integers(0, specials.size, 200_000)]
+    pos = np.abs(rng.normal(0, 4, 4_000_000)).astype(np.float32)  # whole waves inside the fast range
+    for arr in (x, pos):
+        with np.errstate(invalid="ignore"):
+            want = np.sqrt(arr)
+        for op in (7, 9):
+            got = hip.unit_math(op, arr)
+            nan = np.isnan(want)
+            assert np.array_equal(np.isnan(got), nan)
+            assert_same(got[~nan], want[~nan], "square root, op %d" % op)
+
+
 def test_camera_rays_device_vs_oracle(hip, oracle, scenes_mod):
     rng = np.random.default_rng(2)
     for name, W, H, ap in (("cover", 1200, 800, -1.0), ("cover", 1920, 1080, 2.0), ("three", 200, 100, -1.0)):
@@ -944,8 +971,8 @@ def test_colours_that_are_not_bytes_take_the_unpacked_material_records(hip, orac
     """The packed 16-byte material record (rt_shade.h load_material16) holds colours as bytes -- every colour the reference can hold
     (XMLoadColor of an XMCOLOR; the oracle, like the reference, stores its textures as XMCOLOR, so colours off that grid are outside
     the parity contract).  The ABI takes floats all the same: a scene with colours that are NOT byte * (1 / 255) must not be packed
-    (packing would snap them) -- it renders the same bits as under RT_MATS16=0, and other bits than its snapped twin; the snapped
-    scene (packed by default) equals the oracle."""
+    (packing would snap them) -- under RT_MATS16=1 it renders the same bits as with the 48-byte records (the default), and other bits
+    than its snapped twin; the snapped scene, packed, equals the oracle."""
     sc = scenes_mod.build_scene(name, 1, W, H)
     imgs = []
     for delta in (np.float32(3.1e-4), np.float32(0.0)):
@@ -953,11 +980,9 @@ def test_colours_that_are_not_bytes_take_the_unpacked_material_records(hip, orac
         m["rgb0"][::3] = np.clip(m["rgb0"][::3] + delta, 0, 1)
         m["rgb1"][::5] = np.clip(m["rgb1"][::5] + delta, 0, 1)
         sc2 = type(sc)(sc.spheres, m, sc.camera, sc.sun, sc.sky, sc.exposure_scale, sc.name, sc.seed)
-        hip.upload(sc2)
-        sg = hip.render(W, H, 1, 4, 50, 2)
-        hg = hip.download(ldr=False)[0]
+        sg, hg, _ = _render_with_env(monkeypatch, {"RT_MATS16": "1"}, sc2, W, H, 4, seed=2)
         s48, h48, _ = _render_with_env(monkeypatch, {"RT_MATS16": "0"}, sc2, W, H, 4, seed=2)
-        assert_same(hg, h48, "%s, colour offset %g: default vs the 48-byte records" % (name, delta))
+        assert_same(hg, h48, "%s, colour offset %g: RT_MATS16=1 vs the 48-byte records" % (name, delta))
         assert (sg.traversals, sg.segments) == (s48.traversals, s48.segments)
         imgs.append(hg)
         if delta == 0.0:
@@ -1137,7 +1162,7 @@ def _render_with_env(monkeypatch, env, sc, W, H, s1, depth=50, seed=1):
     {"RT_GRID": "2"},                                          # the cell-grid scan (tables in LDS) instead of the matrix-core filter
     {"RT_GRID": "2", "RT_MATS_LDS": "0"},                      # ... with its tables through L2
     {"RT_GRID": "2", "RT_STASH": "0", "RT_SHADOW_GRID": "0"},
-    {"RT_MATS16": "0"},                                        # the 48-byte material records through L2 instead of the packed 16-byte ones
+    {"RT_MATS16": "1"},                                        # the packed 16-byte material records instead of the 48-byte ones through L2
     {"RT_MATS16": "2"},                                        # the packed records staged into LDS (56-record stash)
     {"RT_MATS16": "1", "RT_MATS_LDS": "0", "RT_STASH": "0"},
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
@@ -1161,7 +1186,7 @@ def test_launch_and_layout_knobs_give_the_same_bits(hip, scenes_mod, monkeypatch
                                  {"RT_GRID": "0"}, {"RT_GRID": "0", "RT_TREE_LDS": "0", "RT_STASH": "0"}, {"RT_GRID": "0", "RT_BLOCK_THREADS": "512"},
                                  {"RT_STASH": "0"}, {"RT_STASH": "0", "RT_RAY_CACHE": "0"}, {"RT_BLOCK_THREADS": "256", "RT_BLOCKS_PER_CU": "2"},
                                  {"RT_STASH_CAP": "17"}, {"RT_GRID_SG_LDS": "1"}, {"RT_GRID_QUANT": "1"}, {"RT_GRID_QUANT": "1", "RT_STASH_CAP": "24"},
-                                 {"RT_SHADOW_CELLS": "64"}, {"RT_SHADOW_CELLS": "128", "RT_GRID": "0"}, {"RT_SG_SPH": "1"}, {"RT_SG_SPH": "1", "RT_GRID": "0"}, {"RT_MATS16": "0"}, {"RT_MATS16": "0", "RT_GRID": "0"}],
+                                 {"RT_SHADOW_CELLS": "64"}, {"RT_SHADOW_CELLS": "128", "RT_GRID": "0"}, {"RT_SG_SPH": "1"}, {"RT_SG_SPH": "1", "RT_GRID": "0"}, {"RT_MATS16": "1"}, {"RT_MATS16": "1", "RT_GRID": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in sorted(e.items())))
 def test_hierarchy_scan_knobs_give_the_same_bits(hip, scenes_mod, monkeypatch, env):
     """grid10k (10,004 spheres: the cell-grid scan by default): the bounds hierarchy instead (RT_GRID=0: 2,504 groups, four levels of

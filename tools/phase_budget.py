@@ -35,7 +35,7 @@ SITE_FILES = ("rt_kernels.h", "rt_scan.h", "rt_shade.h", "rt_params.h", "rt_devi
 # region -> phase of the budget (VERDICT r3 #1a's list)
 PHASES = collections.OrderedDict([
     ("ray generation", ["K_GEN", "K_GEN_LANE", "K_PATHLIST", "K_PARTIAL", "P_HALTON"]),
-    ("slow-path divisions (exponent guards failed)", ["M_DIV_SLOW"]),
+    ("slow paths of the divisions and square roots (range guards failed)", ["M_DIV_SLOW", "M_SQRT_SLOW", "M_ROOT_SLOW"]),
     ("queue (block claims)", ["K_NEXTBLOCK", "K_CLAIM"]),
     ("stash push / pop", ["K_POP", "K_POP_LANE", "K_PUSH", "K_PUSH_LANE"]),
     ("scan: operand build, bitmap exchange, result read", ["S_SCAN"]),
@@ -45,14 +45,14 @@ PHASES = collections.OrderedDict([
     ("scan: pooled phase A (ray fetch + four one-sphere bound tests + survivor push)", ["S_ASTEP", "S_ASTEP2", "S_APUSH"]),
     ("scan: exact Sphere::Intersect (phase B)", ["S_DRAIN", "S_BSTEP", "S_BSTEP2"]),
     ("scan: ds_min_u64 merge", ["S_BMIN"]),
-    ("grid scan: ray clip, big spheres, result read", ["G_SCAN", "G_BIG"]),
+    ("grid scan: ray clip, big spheres, result read", ["G_SCAN", "G_BIG", "G_BIGPUSH"]),
     ("grid scan: feed (slab items listed)", ["G_FEED", "G_FEED_LANE"]),
     ("grid scan: item round (ray fetch, slab rows, cell starts)", ["G_ROUND"]),
     ("grid scan: one-sphere bound tests, four per step + survivor push", ["G_STEP", "G_PUSH"]),
     ("grid scan: exact Sphere::Intersect", ["G_DRAIN", "G_BSTEP"]),
     ("grid scan: ds_min_u64 merge", ["G_BMIN"]),
     ("transitions (miss / hit record / far-hit shadow state)", ["K_TRANS_MISS", "K_TRANS_HIT", "K_TRANS_SHADOW"]),
-    ("hit processing: glue (material load, normal, state update)", ["K_PROCESS", "H_PROCESS", "H_INDEXED", "H_FARHIT", "H_MULTI"]),
+    ("hit processing: glue (material load, normal, state update)", ["K_PROCESS", "H_PROCESS", "H_MAT16", "H_INDEXED", "H_FARHIT", "H_MULTI"]),
     ("hit processing: scatter_only", ["H_SCATTER", "H_TRANSPARENT", "H_METAL", "H_OPAQUE", "H_OPAQUE_DIFFUSE"]),
     ("hit processing: shadow_query", ["H_SHADOWQ", "H_SQ_WALK", "H_SQ_CONSIDER", "H_SQ_GROUND", "H_SQ_GTAIL", "H_SQ_ROUND", "H_SQ_TAIL1", "H_SQ_CELL", "H_SQ_ROOTS", "H_SQ_FULL"]),
     ("hit processing: shade_value", ["H_SHADEV", "H_SHADE"]),
@@ -304,19 +304,25 @@ def do_static(cfg):
         if site and path is not None:  # (instructions that took a neighbour's region have no stack of their own)
             copies[site].add(path)
     per = collections.defaultdict(collections.Counter)
+    per_ops = collections.defaultdict(collections.Counter)  # mnemonics per region (tools/opcode_mix.py weighs them by the trip counts)
     for (addr, op, _a), site in zip(ins, sites):
         c = classify(op)
         per[site or "OTHER"][c] += 1
+        per_ops[site or "OTHER"][op] += 1
         if c == "valu" and "_f64" in op:
             per[site or "OTHER"]["valu_f64"] += 1
         if op.startswith("ds_bpermute"):
             per[site or "OTHER"]["ds_bpermute"] += 1
     out = {"config": cfg, "kernel": kernel, "instructions": len(ins), "instructions_shipped_build": len(plain), "debug_build_code_identical": same_code, "instructions_outside_the_persistent_loop_with_loop_lines": hoisted,
            "instruction_mix_debug_build": dict(hg), "instruction_mix_shipped_build": dict(hp), "regions": {k: dict(v, copies=max(1, len(copies.get(k, ())))) for k, v in sorted(per.items())},
+           "region_opcodes": {k: dict(v) for k, v in sorted(per_ops.items())},
            "totals": dict(sum((collections.Counter(v) for v in per.values()), collections.Counter())),
            "site_lines": {fn: [(lo, hi, n) for lo, hi, n in r] for fn, r in regions.items()}}
     path = os.path.join(ROOT, "build", "phase_static_%s.json" % cfg)
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
+    with open(os.path.join(ROOT, "build", "phase_listing_%s.txt" % cfg), "w") as f:  # the kernel, instruction by instruction, with its region
+        for (addr, op, args), site, fr in zip(ins, sites, stacks):
+            f.write("%6x  %-14s %-28s %-60s %s\n" % (addr, site or "-", op, args, " < ".join("%s:%d" % (n[:24], l) for n, _f, l in fr[:3])))
     print(path)
     for k, v in sorted(per.items()):
         print("  %-18s x%d %s" % (k, max(1, len(copies.get(k, ()))), dict(v)))
