@@ -1240,6 +1240,37 @@ def test_closest_hit_unit_runs_the_production_scan(oracle, scenes_mod, monkeypat
         r.close()
 
 
+@pytest.mark.parametrize("name", ["cover", "grid10k"])
+def test_closest_hit_of_rays_whose_direction_is_far_from_unit_length(hip, oracle, scenes_mod, name):
+    """The exact phase divides by a = d.d through Markstein's correction when a is in [2^-19, 2^100] (rt_scan.h pooled_root) and takes
+    square roots through the four-operation form when the discriminant is in [2^-80, inf) (rt_device_math.h sqrt_rn); ONE lane outside
+    sends its whole wave through the compiler's sequences.  Directions scaled by 2^-12 (a = 2^-24) and by 2^52 (a = 2^104), alone and
+    mixed into waves of ordinary rays: t, index, position, normal and uv equal the oracle's list scan.  (With |d| = 2^52 every root
+    is ~1e-15, below the reference's bias of 0.001: those rays exercise the guards and hit nothing, in the oracle as on the device.)"""
+    sc = scenes_mod.build_scene(name, 1, 300, 200)
+    hip.upload(sc)
+    orc = oracle.Oracle()
+    orc.upload(sc)
+    rng = np.random.default_rng(23)
+    n = 64 * 60
+    o = rng.uniform(-10, 10, (n, 3)).astype(np.float32)
+    o[:, 1] = rng.uniform(0.05, 3, n)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:, 1] = -np.abs(d[:, 1]) * np.float32(0.3)
+    scale = np.ones(n, dtype=np.float32)
+    scale[: 64 * 10] = np.float32(2.0 ** -12)          # whole waves of short directions
+    scale[64 * 10: 64 * 20] = np.float32(2.0 ** 52)    # whole waves of long ones
+    mixed = np.arange(64 * 20, n)
+    scale[mixed[::7]] = np.float32(2.0 ** -12)         # one lane in seven: mixed waves
+    scale[mixed[3::11]] = np.float32(2.0 ** 52)
+    rays = np.concatenate([o, d * scale[:, None]], 1).astype(np.float32)
+    hg = hip.unit_closest_hit(rays)
+    ho = orc.closest_hit(rays, accel=oracle.ACCEL_LIST)
+    assert_same(hg, ho, "%s: closest hit of rays with |d| = 2^-12, 1, 2^52" % name)
+    hit = hg[:, 1].view(np.int32) >= 0
+    assert hit[: 64 * 10].sum() > 300 and hit[64 * 10: 64 * 20].sum() == 0 and hit[64 * 20:].sum() > 1000
+
+
 def test_c5_full_size_properties(hip, oracle, scenes_mod):
     """BASELINE config 5 at full size: 10,004 spheres, 4096x4096, spp 64 (1.07 G paths through the hierarchy scan, one
     pass).  Counts, idempotence of a second launch, and six whole-pixel sums + LDR bytes against the oracle."""
