@@ -1330,7 +1330,10 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
                 RT_SITE(G_FEED_LANE);
                 const uint32_t left = (uint32_t)((slabLast - slab) * slabStep) + 1u;
                 cnt = left < kFeed ? left : kFeed;
-                const uint32_t tb = reinterpret_cast<const uint32_t*>(best + lane)[1];
+#ifndef RT_GRID_FEEDSKIP
+#define RT_GRID_FEEDSKIP 1
+#endif
+                const uint32_t tb = RT_GRID_FEEDSKIP ? reinterpret_cast<const uint32_t*>(best + lane)[1] : 0x7f800000u;
                 if (tb < 0x7f800000u) {
                     // where the walk enters the neighbourhood of slab `slab` (grid_slab_rows' sEnter), against the far limit
                     const float uNear = eu > su ? __builtin_fmaxf(__builtin_fminf(su, eu), (float)slab - D - kGridSlack)
@@ -1375,9 +1378,14 @@ RT_DEV void scan_list_grid(const float4* __restrict__ tab, const float4* __restr
                 // the slab's cells r0..r1 are consecutive, and so are their spheres in the scan table
                 eb = (uint32_t)cellStart[iu * nv + r0];
                 ee = (uint32_t)cellStart[iu * nv + r1 + 1];
+#ifndef RT_GRID_ROUNDSKIP
+#define RT_GRID_ROUNDSKIP 0  // 1: a consumer re-checks its slab against the ray's closest hit so far before testing it (round 3; -1.5 % on grid10k: the feed's own check is enough)
+#endif
+#if RT_GRID_ROUNDSKIP
                 // (a slab the ray enters beyond its closest hit so far has nothing to add)
                 const uint32_t tb0 = reinterpret_cast<const uint32_t*>(best + r)[1];
                 if (tb0 < 0x7f800000u && __builtin_fmaf(sEnter, ftf - ftn, ftn) > __uint_as_float(tb0) * (1.f + 0x1p-10f)) ee = eb;
+#endif
             }
             // four spheres per step; every lane runs as many steps as the longest run of the round needs
             while (__ballot(eb < ee) != 0ull) {
